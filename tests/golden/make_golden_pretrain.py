@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the LM-pretrain-stack MoE layers by RUNNING THE REFERENCE classes.
+
+Build-container only (needs /root/reference).  The pretrain package does not import as shipped
+(circular import + missing files), so this script builds stub *packages* in
+sys.modules whose __path__ points into the reference, loads the three mixins, the entropy /
+distributed_ops helpers and layers/cvmm.py by file path, and then imports
+layers.moe.{register,moe,smoe,competesmoe,deepseekv2,deepseekv3} normally.
+
+The two Triton kernels in layers/cvmm.py cannot run without a GPU.  `cvmm()` is therefore
+replaced by `cvmm_cpu` below -- OUR restatement of the documented index semantics
+(cvmm.py:99-168, 363-398, 481-483) with plain torch ops -- before the layer modules are imported.
+Everything else (gating, top-k, index preparation `cvmm_prepare_sel2`, losses, schedule, mixins)
+is the reference's own code.  The fixtures say so in meta["cvmm"].
+
+Usage:  python tests/golden/make_golden_pretrain.py   (writes tests/golden/pretrain_*.pt)
+"""
+import importlib
+import importlib.util
+import os
+import sys
+import tempfile
+import types
+
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/moe_pretrain_model"
+
+_CVMM_OUT_DTYPE = [torch.float32]   # emulates cvmm.get_dtype(): autocast dtype or fp32
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def cvmm_cpu(x, sel, keys):
+    """CPU restatement of reference cvmm(): out[out_index[m]] = x[sel_index[m]] @ keys[sel[m]],
+    operands cast to the op dtype, fp32 accumulate, optional weighted K-reduction."""
+    op = _CVMM_OUT_DTYPE[0]
+    xf = x.flatten(end_dim=-2)
+    ssel = sel.sel.flatten().long()
+    rows = xf[sel.sel_index.long()].to(op)
+    M, Dout = ssel.shape[0], keys.shape[-1]
+    prod = torch.zeros(M, Dout, dtype=op)
+    for e in range(keys.shape[0]):
+        msk = ssel == e
+        if msk.any():
+            acc = rows[msk].float() @ keys[e].to(op).float()
+            prod = prod.index_put((msk.nonzero().squeeze(-1),), acc.to(op))
+    dst = sel.sel_index if sel.out_index is None else sel.out_index
+    out = torch.zeros(M, Dout, dtype=op).index_put((dst.long(),), prod)
+    out = out.view(*sel.sel.shape, Dout)
+    if sel.reduction_weight is not None:
+        w = sel.reduction_weight
+        out = out.view(*w.shape, Dout)
+        out = (w.unsqueeze(-2).type_as(out) @ out).squeeze(-2)
+    return out
+
+
+def _import_reference():
+    if "layers.moe.smoe" in sys.modules:
+        return sys.modules["layers.moe.register"].get_moe
+    fw = _pkg("framework", os.path.join(REF, "framework"))
+    fwl = _pkg("framework.layers", os.path.join(REF, "framework", "layers"))
+    fwu = _pkg("framework.utils", os.path.join(REF, "framework", "utils"))
+
+    # minimal stand-in for framework.utils.U (only apply_to_tensors is used by LoggingLayer.log)
+    U = types.ModuleType("framework.utils.U")
+
+    def apply_to_tensors(d, fn):
+        if torch.is_tensor(d):
+            return fn(d)
+        if isinstance(d, (list, tuple)):
+            return type(d)(apply_to_tensors(v, fn) for v in d)
+        if isinstance(d, dict):
+            return {k: apply_to_tensors(v, fn) for k, v in d.items()}
+        return d
+    U.apply_to_tensors = apply_to_tensors
+    fwu.U = U
+    ent = _load("framework.utils.entropy", os.path.join(REF, "framework", "utils", "entropy.py"))
+    dops = _load("framework.utils.distributed_ops", os.path.join(REF, "framework", "utils", "distributed_ops.py"))
+    for k in ("entropy", "entropy_l", "relative_perplexity", "relative_perplexity_l", "perplexity"):
+        setattr(fwu, k, getattr(ent, k))
+    fwu.distributed_ops = dops
+    fwu.entropy = ent.entropy
+    fw.utils = fwu
+    ll = _load("framework.layers.logging_layer", os.path.join(REF, "framework", "layers", "logging_layer.py"))
+    rl = _load("framework.layers.regularized_layer", os.path.join(REF, "framework", "layers", "regularized_layer.py"))
+    ol = _load("framework.layers.once_per_iter_layer", os.path.join(REF, "framework", "layers", "once_per_iter_layer.py"))
+    fwl.LoggingLayer, fwl.RegularizedLayer, fwl.OncePerIterLayer = ll.LoggingLayer, rl.RegularizedLayer, ol.OncePerIterLayer
+    fw.layers = fwl
+
+    lay = _pkg("layers", os.path.join(REF, "layers"))
+    cv = _load("layers.cvmm", os.path.join(REF, "layers", "cvmm.py"))
+    cv.cvmm = cvmm_cpu
+    lay.cvmm = cvmm_cpu
+    lay.cvmm_prepare_sel = cv.cvmm_prepare_sel
+    _pkg("layers.moe", os.path.join(REF, "layers", "moe"))
+    for m in ("register", "moe", "smoe", "competesmoe", "deepseekv2", "deepseekv3"):
+        importlib.import_module(f"layers.moe.{m}")
+    return sys.modules["layers.moe.register"].get_moe
+
+
+def make_args(**kw):
+    base = dict(
+        moe_name="smoe", stop_after=10, warm_up=0.0, rate_flip=1.0, max_compete_in_iter=8,
+        balance_loss_coef=0.01, balance_loss_coef_comp=0.02, router_loss_coef=0.03, router_theta=0.5,
+        in_topk=False, hybrid=False, tribrid=False, balance_affinity=False,
+        is_cosine=False, is_norm_weight=False, norm_sigmoid=False, scale_weight=1.0, test_only=False,
+    )
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def run_case(name, moe_name, bf16, *, B=2, N=64, D=64, E=8, F_=32, K=2, competition=False,
+             args_kw=None, bias=False, seed=0, full=True):
+    get_moe = _import_reference()
+    args = make_args(moe_name=moe_name, **(args_kw or {}))
+    torch.manual_seed(seed)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)  # set_total_steps appends to ./file_path.txt (competesmoe.py:218-221)
+    try:
+        layer = get_moe(moe_name)(D, E, F_, n_heads=K, activation=F.relu, bias=bias, log_interval=None, args=args)
+        layer.train()
+        if bias:
+            g0 = torch.Generator().manual_seed(seed + 5)
+            for p in (layer.bias, layer.o_bias, getattr(layer, "bias_shared", None)):
+                if p is not None:
+                    p.data = torch.randn(p.shape, generator=g0) * 0.1
+        fx = {"meta": dict(name=name, moe_name=moe_name, bf16=bf16, B=B, N=N, D=D, E=E, F=F_, K=K, bias=bias,
+                           competition=competition, args=vars(args),
+                           cvmm="cvmm() replaced by a CPU restatement in make_golden_pretrain.py (Triton needs a GPU)")}
+        kw = {}
+        if moe_name == "competesmoe":
+            torch.manual_seed(1234)
+            layer.prob_flips_final = {}
+            pf = layer.set_total_steps(id_layer=0)
+            if not competition:
+                layer.prob_flips_final[0] = torch.zeros_like(layer.prob_flips_final[0])
+            layer.set_current_steps(3)
+            fx["prob_flips"] = layer.prob_flips_final[0].clone()
+            kw["id_layer"] = 0
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn(B, N, D, generator=g)
+        dy = torch.randn(B, N, D, generator=g)
+        fx["state"] = {k: v.clone() for k, v in layer.state_dict().items()}
+        if full:
+            fx["x"], fx["dy"] = x.clone(), dy.clone()
+        else:
+            fx["x_seed"] = seed + 1
+
+        _CVMM_OUT_DTYPE[0] = torch.bfloat16 if bf16 else torch.float32
+        xg = x.clone().requires_grad_(True)
+        layer.regularization_present = True
+        if bf16:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = layer(xg, **kw)
+                reg = layer.get_reg_loss()
+        else:
+            out = layer(xg, **kw)
+            reg = layer.get_reg_loss()
+        fx["output"] = out.detach().clone()
+        fx["reg_loss"] = {k: v.detach().clone() for k, v in reg.items()}
+        loss = (out.float() * dy).sum() + sum(v.float() for v in reg.values())
+        loss.backward()
+        if full:
+            fx["x_grad"] = xg.grad.clone()
+            fx["grads"] = {k: (p.grad.clone() if p.grad is not None else None) for k, p in layer.named_parameters()}
+        else:
+            fx["x_grad_sum"] = xg.grad.double().sum()
+            fx["x_grad_norm"] = xg.grad.double().norm()
+            fx["grad_norms"] = {k: p.grad.double().norm() for k, p in layer.named_parameters() if p.grad is not None}
+        with torch.no_grad():
+            gl = layer.compute_gate(x)
+            fx["gate_logits"] = gl.clone()
+    finally:
+        os.chdir(cwd)
+        _CVMM_OUT_DTYPE[0] = torch.float32
+    path = os.path.join(HERE, f"pretrain_{name}.pt")
+    torch.save(fx, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB | out", tuple(out.shape),
+          {k: round(float(v), 6) for k, v in fx["reg_loss"].items()})
+
+
+def cvmm_index_case():
+    """Pin cvmm_prepare_sel2 index semantics (reference function, integer work)."""
+    _import_reference()
+    cv = sys.modules["layers.cvmm"]
+    g = torch.Generator().manual_seed(3)
+    sel = torch.randint(0, 8, (2, 16, 2), generator=g, dtype=torch.int32)
+    s = cv.cvmm_prepare_sel2(sel)
+    fx = {"sel": sel, "sorted": s.sel.clone(), "sel_index": s.sel_index.clone(), "out_index": s.out_index.clone()}
+    torch.save(fx, os.path.join(HERE, "pretrain_cvmm_sel.pt"))
+    print("wrote pretrain_cvmm_sel.pt")
+
+
+def schedule_case():
+    get_moe = _import_reference()
+    args = make_args(moe_name="competesmoe", stop_after=40, warm_up=0.25, rate_flip=0.6, max_compete_in_iter=2)
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())
+    try:
+        layers = [get_moe("competesmoe")(16, 4, 8, n_heads=2, activation=F.relu, log_interval=None, args=args)
+                  for _ in range(4)]
+        torch.manual_seed(7)
+        prev = {}
+        for i, l in enumerate(layers):   # transformer_lm_mixin.py:259-267 protocol
+            l.prob_flips_final = prev
+            prev = l.set_total_steps(id_layer=i)
+    finally:
+        os.chdir(cwd)
+    fx = {"meta": dict(seed=7, args=vars(args)), "prob_flips": {int(k): v.clone() for k, v in prev.items()},
+          "step_warm": layers[0].step_warm, "flip_steps": layers[0].flip_steps}
+    torch.save(fx, os.path.join(HERE, "pretrain_schedule.pt"))
+    print("wrote pretrain_schedule.pt")
+
+
+def main():
+    torch.set_num_threads(4)
+    for bf16, tag in ((False, "fp32"), (True, "bf16")):
+        run_case(f"smoe_{tag}", "smoe", bf16)
+        run_case(f"smoe_bias_{tag}", "smoe", bf16, bias=True)
+        run_case(f"competesmoe_router_{tag}", "competesmoe", bf16, competition=False)
+        run_case(f"competesmoe_comp_{tag}", "competesmoe", bf16, competition=True)
+        run_case(f"competesmoe_comp_hybrid_{tag}", "competesmoe", bf16, competition=True,
+                 args_kw=dict(hybrid=True, balance_affinity=True))
+        run_case(f"deepseekv2_{tag}", "deepseekv2", bf16, K=3)
+        run_case(f"deepseekv3_{tag}", "deepseekv3", bf16, K=3)
+    # BASELINE config 1: D=256, E=8, K=2, F=128, T=1024 as [4,256] -- checksums only
+    run_case("config1_smoe_fp32", "smoe", False, B=4, N=256, D=256, E=8, F_=128, K=2, full=False)
+    cvmm_index_case()
+    schedule_case()
+
+
+if __name__ == "__main__":
+    main()
