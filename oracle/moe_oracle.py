@@ -1,0 +1,352 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+A from-scratch CPU restatement (plain PyTorch CPU ops, fp32 and bf16) of the sparse-MoE hot path of
+Fsoft-AIC/CompeteSMoE.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
+may import this module, and only as the checker / the timed CPU baseline.  The shipped path
+(`competesmoe_amd`) never imports it and fails loudly when its HIP library is missing.
+
+Pinned by: `tests/golden/*.pt`, produced by running the reference classes themselves in the build
+container (`tests/golden/make_golden_{llava,pretrain}.py`); `tests/test_oracle_golden.py` checks every
+function below against them.  The reference has no unit tests / golden vectors of its own for this
+path, so those captured outputs are the pin.
+
+Every function cites the reference file:line it restates (paths relative to the reference root).
+Gradients come from torch autograd over these differentiable restatements.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------
+# Router  (moe_model/model/moe/moe.py:113-132, smoe.py:42-44, competesmoe.py:301-320)
+# --------------------------------------------------------------------------------------------
+def gate_logits(x: torch.Tensor, w_gate: torch.Tensor) -> torch.Tensor:
+    """`self.gate(x)`: Linear(D->E, bias=False), output in x.dtype (smoe.py:42)."""
+    return F.linear(x, w_gate)
+
+
+def topk_lowest_index(v: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Top-k, descending, ties broken by LOWEST index (the build's defined tie rule; torch.topk
+    on CPU has no stable rule, SURVEY.md §7 hard parts).  Iterative arg-max so it is exact."""
+    vals, idxs = [], []
+    work = v.clone()
+    for _ in range(k):
+        m, i = work.max(dim=-1, keepdim=True)   # torch.max returns the first (lowest) index on ties
+        vals.append(m)
+        idxs.append(i)
+        work = work.scatter(-1, i, float("-inf"))
+    return torch.cat(vals, -1), torch.cat(idxs, -1)
+
+
+def router_topk(logits: torch.Tensor, k: int, x_dtype: torch.dtype, use_torch_topk: bool = False):
+    """softmax(fp32) -> top-k -> renormalise (moe.py:129-130, smoe.py:44).
+
+    The denominator is rounded to x.dtype first (`torch.sum(...).to(x.dtype)`), the quotient stays fp32."""
+    sm = F.softmax(logits, dim=-1, dtype=torch.float32)
+    if use_torch_topk:
+        w, idx = torch.topk(sm, k)
+    else:
+        idx = topk_lowest_index(sm.detach(), k)[1]
+        w = torch.gather(sm, -1, idx)
+    w = w / torch.sum(w, dim=-1, keepdim=True).to(x_dtype)
+    return w, idx, sm
+
+
+# --------------------------------------------------------------------------------------------
+# Aux losses (moe.py:71-110, 214-226; competesmoe.py:180-218, 322-335)
+# --------------------------------------------------------------------------------------------
+def zloss(logits: torch.Tensor) -> torch.Tensor:
+    """moe.py:71-88: mean(logsumexp(logits)^2), in the logits' dtype."""
+    return torch.square(torch.logsumexp(logits, dim=-1)).mean()
+
+
+def balanceloss(selected: torch.Tensor, softmax: torch.Tensor, n_experts: int) -> torch.Tensor:
+    """moe.py:90-110: mean_n(softmax) * mean_n(onehot(top-1 column)), mean over (b,e), * E^2."""
+    proxy = softmax.mean(dim=-2)
+    onehot = F.one_hot(selected[..., 0], n_experts).float()
+    dens = onehot.mean(dim=-2)
+    return (proxy * dens).mean() * float(n_experts ** 2)
+
+
+def combine_loss(selected, softmax, logits, n_experts, balance_coef, z_coef):
+    """moe.py:214-226."""
+    bal = balanceloss(selected, softmax, n_experts)
+    z = zloss(logits)
+    return bal * balance_coef + z * z_coef, bal, z
+
+
+def router_loss(gate_softmax, affinity_softmax):
+    """competesmoe.py:322-335: MSE."""
+    return F.mse_loss(gate_softmax, affinity_softmax)
+
+
+def experts_diversity_loss(topk_out: torch.Tensor) -> torch.Tensor:
+    """competesmoe.py:180-218: mean over T*K*K of off-diagonal cosine similarities (diag zeroed, counted)."""
+    eo = topk_out.to(torch.float32)
+    B, N, K, D = eo.shape
+    nrm = F.normalize(eo, p=2, dim=-1).view(B * N, K, D)
+    sim = torch.bmm(nrm, nrm.transpose(1, 2))
+    sim = sim * (1 - torch.eye(K))
+    return sim.mean()
+
+
+def entropy_balance(logits: torch.Tensor) -> torch.Tensor:
+    """moe_pretrain_model/layers/moe/moe.py:323-332 with framework/utils/entropy.py:21-22 and
+    distributed_ops.py:47-58 (non-distributed branch): -H(logmeanexp_n log_softmax(logits)), mean over batch."""
+    sel = logits.flatten(1, -2)
+    ls = F.log_softmax(sel, dim=-1)
+    lm = ls.float().logsumexp(-2) - math.log(ls.shape[-2])
+    ent = -(lm * lm.exp()).sum(-1)
+    return -ent.mean()
+
+
+# --------------------------------------------------------------------------------------------
+# Expert FFN + compute_moe (LLaVA stack: moe.py:172-213; experts: siglip_smoe.py:85-97, builder.py:61-65)
+# --------------------------------------------------------------------------------------------
+ACTS = {
+    "gelu": lambda h: F.gelu(h),
+    "gelu_tanh": lambda h: F.gelu(h, approximate="tanh"),
+    "relu": lambda h: F.relu(h),
+    "silu": lambda h: F.silu(h),
+    "none": lambda h: h,
+}
+
+
+def expert_ffn(x, w1, b1, w2, b2, act: str):
+    """Linear(D,F)+b -> act -> Linear(F,Dout)+b  (every intermediate rounded to x.dtype, as nn.Linear does)."""
+    h = F.linear(x, w1, b1)
+    a = ACTS[act](h)
+    return F.linear(a, w2, b2)
+
+
+def compute_moe(x, selected, weights, experts: Sequence[Tuple], act: str, out_dim: int):
+    """moe.py:172-213: loop over experts in index order; results[b,t] += w[b,t,k] * expert(x[b,t]).
+
+    `results` lives in x.dtype: every `+=` computes in fp32 (fp32 weight * x.dtype out) and rounds back."""
+    B, N, D = x.shape
+    results = torch.zeros(B, N, out_dim, dtype=x.dtype)
+    for i, (w1, b1, w2, b2) in enumerate(experts):
+        bi, ti, ki = torch.where(selected == i)
+        out = expert_ffn(x[bi, ti], w1, b1, w2, b2, act)
+        contrib = weights[bi, ti, ki].unsqueeze(0).T * out
+        results = results.index_put((bi, ti), (results[bi, ti] + contrib).to(x.dtype))
+    return results
+
+
+# --------------------------------------------------------------------------------------------
+# Competition policy (competesmoe.py:219-259)
+# --------------------------------------------------------------------------------------------
+def competition_policy(x, experts, act, k, norm_sigmoid=False, use_torch_topk=False):
+    """All experts densely; affinity = mean_D softplus(out_i) in x.dtype; softmax fp32; top-k on RAW affinity."""
+    B, N, D = x.shape
+    E = len(experts)
+    outs = [expert_ffn(x, *experts[i], act) for i in range(E)]
+    aff = torch.stack([torch.mean(F.softplus(o), dim=-1) for o in outs], dim=-1).to(x.dtype)
+    aff_sm = F.softmax(aff, dim=-1, dtype=torch.float32)
+    score = torch.sigmoid(aff) if norm_sigmoid else aff
+    if use_torch_topk:
+        w, idx = torch.topk(score, k)
+    else:
+        idx = topk_lowest_index(score.detach(), k)[1]
+        w = torch.gather(score, -1, idx)
+    w = w / torch.sum(w, dim=-1, keepdim=True).to(x.dtype)
+    all_out = torch.stack(outs, dim=2)                       # [B,N,E,Dout]
+    topk_out = torch.gather(all_out, 2, idx.unsqueeze(-1).expand(B, N, k, all_out.size(-1)))
+    return w, idx, aff_sm, aff, topk_out
+
+
+# --------------------------------------------------------------------------------------------
+# LLaVA-stack layer forwards
+# --------------------------------------------------------------------------------------------
+def llava_smoe_forward(x, w_gate, experts, act, k, args, out_dim=None, forced_idx=None):
+    """SMoeLayer.forward (smoe.py:39-64).  Returns (output, aux, infor_aux, stages)."""
+    E = w_gate.shape[0]
+    out_dim = out_dim or experts[0][2].shape[0]
+    lg = gate_logits(x, w_gate)
+    w, idx, sm = router_topk(lg, k, x.dtype)
+    if forced_idx is not None:   # evaluate with the reference's own (tie-broken) indices
+        idx = forced_idx
+        w = torch.gather(sm, -1, idx)
+        w = w / torch.sum(w, dim=-1, keepdim=True).to(x.dtype)
+    out = compute_moe(x, idx, w, experts, act, out_dim)
+    aux = torch.tensor(0.0, dtype=x.dtype)
+    infor = {}
+    if x.requires_grad:
+        aux, bal, z = combine_loss(idx, sm, lg, E, args.balance_loss_coef, args.router_z_loss_coef)
+        infor = {"balance_loss": bal.detach(), "router_z_loss": z.detach()}
+    return out, aux, infor, dict(gate_logits=lg, gate_softmax=sm, selected_experts=idx, weights=w)
+
+
+def llava_competesmoe_forward(x, w_gate, experts, act, k, args, competing: bool, out_dim=None,
+                              forced_idx=None, forced_aff_idx=None):
+    """CompeteSMoE.forward (competesmoe.py:337-415); `competing` = the scheduled-branch test (:347)."""
+    E = w_gate.shape[0]
+    out_dim = out_dim or experts[0][2].shape[0]
+    lg = gate_logits(x, w_gate)
+    gw, gidx, gsm = router_topk(lg, k, x.dtype)
+    if forced_idx is not None:
+        gidx = forced_idx
+        gw = torch.gather(gsm, -1, gidx)
+        gw = gw / torch.sum(gw, dim=-1, keepdim=True).to(x.dtype)
+    stages = dict(gate_logits=lg, gate_softmax=gsm, selected_experts=gidx, weights=gw)
+    aux = torch.tensor(0.0, dtype=x.dtype)
+    infor = {}
+    if x.requires_grad and competing:
+        aw, aidx, asm, aff, topk_out = competition_policy(x, experts, act, k, getattr(args, "norm_sigmoid", False))
+        if forced_aff_idx is not None:
+            aidx = forced_aff_idx
+            score = torch.sigmoid(aff) if getattr(args, "norm_sigmoid", False) else aff
+            aw = torch.gather(score, -1, aidx)
+            aw = aw / torch.sum(aw, dim=-1, keepdim=True).to(x.dtype)
+            allo = torch.stack([expert_ffn(x, *experts[i], act) for i in range(E)], dim=2)
+            topk_out = torch.gather(allo, 2, aidx.unsqueeze(-1).expand(*aidx.shape, allo.size(-1)))
+        rl = router_loss(gsm, asm.detach())
+        if getattr(args, "hybrid", False):
+            g_top = torch.gather(gsm, -1, aidx)
+            a_top = torch.gather(asm, -1, aidx)
+            rl = rl + router_loss(g_top, a_top.detach()) * args.router_theta
+        div = experts_diversity_loss(topk_out)
+        bal = balanceloss(aidx, asm, E)
+        aux = rl * args.router_loss_coef + div * args.diversity_loss_coef + bal * args.bal_comp_loss_coef
+        out = compute_moe(x, aidx, aw, experts, act, out_dim)
+        infor = {"balance_loss": bal.detach(), "diversity_loss": div.detach(), "routerloss": rl.detach()}
+        stages.update(aff_weights=aw, aff_selected=aidx, aff_softmax=asm, aff_scores=aff, aff_topk_out=topk_out)
+    else:
+        out = compute_moe(x, gidx, gw, experts, act, out_dim)
+        if x.requires_grad:
+            aux, bal, z = combine_loss(gidx, gsm, lg, E, args.balance_loss_coef, args.router_z_loss_coef)
+            infor = {"balance_loss": bal.detach(), "router_z_loss": z.detach()}
+    return out, aux, infor, stages
+
+
+def llava_shared_forward(x, w_gate, experts, act, k, args, mode: str, out_dim=None, forced_idx=None):
+    """MoEShareLayer.forward: `smoe_share` (shard_smoe.py:38-67, 0.5/0.5 mix) and `deepseekv3`
+    (deepseekv3.py:35-56, shared + routed; aux always computed).  w_gate has E-1 rows; top-(K-1)."""
+    Er = w_gate.shape[0]
+    out_dim = out_dim or experts[0][2].shape[0]
+    lg = gate_logits(x, w_gate)
+    w, idx, sm = router_topk(lg, k - 1, x.dtype)
+    if forced_idx is not None:
+        idx = forced_idx
+        w = torch.gather(sm, -1, idx)
+        w = w / torch.sum(w, dim=-1, keepdim=True).to(x.dtype)
+    routed = compute_moe(x, idx, w, experts[:Er], act, out_dim)
+    shared = expert_ffn(x, *experts[Er], act)
+    out = torch.zeros_like(routed)
+    if mode == "smoe_share":
+        out = out + (shared * 0.5 + routed * 0.5)
+    else:
+        out = out + (shared + routed)
+    aux = torch.tensor(0.0, dtype=x.dtype)
+    infor = {}
+    if x.requires_grad or mode == "deepseekv3":
+        aux, bal, z = combine_loss(idx, sm, lg, Er, args.balance_loss_coef, args.router_z_loss_coef)
+        infor = {"balance_loss": bal.detach(), "router_z_loss": z.detach()}
+    return out, aux, infor, dict(gate_logits=lg, gate_softmax=sm, selected_experts=idx, weights=w)
+
+
+# --------------------------------------------------------------------------------------------
+# Competition schedule (competesmoe.py:35-176 / pretrain competesmoe.py:123-273)
+# --------------------------------------------------------------------------------------------
+def make_prob_flips(flip_steps: int, rate_flip: float, max_compete_in_iter: int,
+                    prev: Dict[int, torch.Tensor]) -> torch.Tensor:
+    """One `torch.rand(1)` per slot; cap layers competing per step by shifting left then right (:108-130)."""
+    freq = torch.zeros(flip_steps, dtype=torch.int)
+    for v in prev.values():
+        freq += v.int()
+    cur = [False] * flip_steps
+    for i in range(flip_steps):
+        if torch.rand(1).item() < rate_flip:
+            if freq[i] < max_compete_in_iter:
+                cur[i] = True
+                freq[i] += 1
+            else:
+                found = False
+                for j in range(i - 1, -1, -1):
+                    if freq[j] < max_compete_in_iter and not cur[j]:
+                        cur[j] = True
+                        freq[j] += 1
+                        found = True
+                        break
+                if not found:
+                    for j in range(i + 1, flip_steps):
+                        if freq[j] < max_compete_in_iter and not cur[j]:
+                            cur[j] = True
+                            freq[j] += 1
+                            break
+    return torch.tensor(cur, dtype=torch.bool)
+
+
+# --------------------------------------------------------------------------------------------
+# Pretrain stack: cvmm index semantics (moe_pretrain_model/layers/cvmm.py)
+# --------------------------------------------------------------------------------------------
+def bin_tokens(sel: torch.Tensor, n_experts: int):
+    """Stable counting sort of the flattened [T,K] expert ids -- the build's deterministic replacement for the
+    reference's unstable `fsel.sort()` (cvmm.py:580-593).  Returns (counts[E], offsets[E+1], perm[T*K]) where
+    perm[m] is the flat (t*K+k) index held by sorted slot m; in_index = perm // K, out_index = perm."""
+    f = sel.flatten().long()
+    perm = torch.sort(f, stable=True).indices
+    counts = torch.bincount(f, minlength=n_experts)
+    offsets = torch.zeros(n_experts + 1, dtype=torch.long)
+    offsets[1:] = counts.cumsum(0)
+    return counts, offsets, perm
+
+
+def cvmm_ref(x, sel_sorted, in_index, out_index, keys, op_dtype, reduction_weight=None):
+    """cvmm.py:99-168, 363-398: out[out_index[m]] = x[in_index[m]] @ keys[sel_sorted[m]] (operands in op dtype,
+    fp32 accumulate, rounded to op dtype); optional weighted K-reduction as a [..,1,K]@[..,K,D] bmm (:481-483)."""
+    xf = x.flatten(end_dim=-2)
+    rows = xf[in_index.long()].to(op_dtype)
+    M, Dout = in_index.shape[0], keys.shape[-1]
+    prod = torch.zeros(M, Dout, dtype=op_dtype)
+    ss = sel_sorted.flatten().long()
+    for e in range(keys.shape[0]):
+        m = (ss == e).nonzero().squeeze(-1)
+        if m.numel():
+            prod = prod.index_put((m,), (rows[m].float() @ keys[e].to(op_dtype).float()).to(op_dtype))
+    out = torch.zeros(M, Dout, dtype=op_dtype).index_put((out_index.long(),), prod)
+    if reduction_weight is not None:
+        w = reduction_weight
+        out = out.view(*w.shape, Dout)
+        out = (w.unsqueeze(-2).type_as(out) @ out).squeeze(-2)
+    return out
+
+
+def pretrain_ffn(x, idx, weights, keys, values, act, op_dtype, bias=None, o_bias=None):
+    """compute_scores + second cvmm with reduction_weight (moe.py:397-416, smoe.py:240-248)."""
+    B, N, D = x.shape
+    K = idx.shape[-1]
+    E = keys.shape[0]
+    _, _, perm = bin_tokens(idx, E)
+    ssel = idx.flatten()[perm]
+    scores = cvmm_ref(x, ssel, perm // K, perm, keys, op_dtype).view(B, N, K, -1)
+    if bias is not None:
+        scores = scores + bias[idx.long()]
+    scores = ACTS[act](scores)
+    out = cvmm_ref(scores, ssel, perm, perm, values, op_dtype, reduction_weight=weights)
+    out = out.view(B, N, -1)
+    if o_bias is not None:
+        out = out + o_bias
+    return out
+
+
+def pretrain_dense_affinity(x, keys, values, act, k, x_dtype):
+    """competition_policy_mlp_faster (pretrain competesmoe.py:381-414)."""
+    B, N, D = x.shape
+    eo = torch.matmul(x.view(-1, D), keys)
+    eo = ACTS[act](eo)
+    eo = torch.matmul(eo, values).transpose(1, 0)        # [T,E,D]
+    aff = torch.mean(F.softplus(eo), dim=-1).view(B, N, -1)
+    asm = F.softmax(aff, dim=-1, dtype=torch.float32)
+    idx = topk_lowest_index(aff.detach(), k)[1]
+    w = torch.gather(aff, -1, idx)
+    w = w / torch.sum(w, dim=-1, keepdim=True).to(x_dtype)
+    eo = eo.reshape(B, N, *eo.shape[1:])
+    topk_out = torch.gather(eo, 2, idx.unsqueeze(-1).expand(B, N, k, eo.size(-1)))
+    return w, idx, asm, aff, topk_out

@@ -187,6 +187,15 @@ def run_case(name, moe_name, bf16, *, B=2, N=64, D=64, E=8, F_=32, K=2, competit
         with torch.no_grad():
             gl = layer.compute_gate(x)
             fx["gate_logits"] = gl.clone()
+            if competition:
+                _CVMM_OUT_DTYPE[0] = torch.bfloat16 if bf16 else torch.float32
+                if bf16:
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        aw, aidx, asm, aff, _ = layer.competition_policy_mlp_faster(x)
+                else:
+                    aw, aidx, asm, aff, _ = layer.competition_policy_mlp_faster(x)
+                fx["aff_weights"], fx["aff_selected"] = aw.clone(), aidx.clone()
+                fx["aff_softmax"], fx["aff_scores"] = asm.clone(), aff.clone()
     finally:
         os.chdir(cwd)
         _CVMM_OUT_DTYPE[0] = torch.float32
