@@ -1,0 +1,230 @@
+// C ABI (include/csmoe.h): argument validation, fast/generic kernel selection, error strings.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+// ---- kernels implemented in the other translation units
+int gg_generic_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                        const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                        const void* aux, int64_t ldc, int epilogue, int act, int dtype, const void* single_B,
+                        const void* single_bias, hipStream_t st);
+int gg_generic_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
+                     void* const* c_ptrs, int64_t ldc, int dtype, int out_dtype, int accumulate, int single_M, void* single_C,
+                     hipStream_t st);
+bool gg_fast_rowspace_ok(int64_t lda, int64_t ldb, int64_t ldc, int M, int N, int Kd, const void* A, const void* C);
+int gg_fast_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                     const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                     const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
+                     hipStream_t st);
+bool gg_fast_wgrad_ok(int64_t lda, int64_t ldb, int64_t ldc, int M, int Na, int Nb, const void* A, const void* B);
+int gg_fast_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
+                  void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st);
+int k_router_select(const void*, int, int, int, int, int, int, float*, int32_t*, float*, hipStream_t);
+int k_router_select_bwd(const void*, int, int, int, int, int, int, const float*, const int32_t*, const float*, const float*,
+                        const float*, void*, hipStream_t);
+int64_t k_bin_workspace_bytes(int n, int E);
+int k_bin_tokens(const int32_t*, int, int, int32_t*, int32_t*, int32_t*, int32_t*, void*, hipStream_t);
+int k_dispatch_rows(const void*, const int32_t*, int, void*, int, int, int, hipStream_t);
+int k_combine(const void*, const int32_t*, const int32_t*, const float*, const void*, const void*, void*, int, int, int, int, int,
+              hipStream_t);
+int k_combine_bwd(const void*, const void*, const int32_t*, const float*, void*, float*, int, int, int, int, hipStream_t);
+int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, void*, int, int, hipStream_t);
+int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
+int k_softplus_mean_bwd(const void*, const void*, const void*, void*, int, int, int, hipStream_t);
+
+static thread_local char g_err[512] = "";
+
+void csmoe_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline bool dtype_ok(int d) { return d == CSMOE_F32 || d == CSMOE_BF16; }
+static inline int esize(int d) { return d == CSMOE_F32 ? 4 : 2; }
+
+extern "C" {
+
+int csmoe_version(void) { return 100; }
+const char* csmoe_last_error(void) { return g_err; }
+
+int csmoe_device_info(int* n_cu, int* lds_bytes, char* name, int name_len) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { csmoe_set_error("hipGetDevice: %s", hipGetErrorString(e)); return CSMOE_ERR_LAUNCH; }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) { csmoe_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return CSMOE_ERR_LAUNCH; }
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (lds_bytes) *lds_bytes = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (name && name_len > 0) { strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+  return CSMOE_OK;
+}
+
+int csmoe_gate_logits(const void* x, const void* w_gate, void* logits, int T, int D, int E, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype), "gate_logits: bad dtype %d", dtype);
+  CSMOE_CHECK_ARG(T >= 0 && D > 0 && E > 0, "gate_logits: bad shape T=%d D=%d E=%d", T, D, E);
+  CSMOE_CHECK_ARG(x && w_gate && logits, "gate_logits: null pointer");
+  if (T == 0) return CSMOE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  // one dense "expert" over all T rows: logits = x @ w_gate^T
+  if (dtype == CSMOE_BF16 && gg_fast_rowspace_ok(D, D, E, T, E, D, x, logits))
+    return gg_fast_rowspace(x, D, nullptr, CSMOE_B_NK, D, nullptr, nullptr, 1, T, E, D, logits, nullptr, nullptr, E,
+                            CSMOE_EPI_PLAIN, CSMOE_ACT_NONE, w_gate, nullptr, st);
+  return gg_generic_rowspace(x, D, nullptr, CSMOE_B_NK, D, nullptr, nullptr, 1, T, E, D, logits, nullptr, nullptr, E,
+                             CSMOE_EPI_PLAIN, CSMOE_ACT_NONE, dtype, w_gate, nullptr, st);
+}
+
+int csmoe_router_select(const void* scores, int dtype, int T, int E, int K, int sel_mode, int round_sum_bf16, float* softmax,
+                        int32_t* idx, float* w, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype), "router_select: bad dtype %d", dtype);
+  CSMOE_CHECK_ARG(T >= 0 && E > 0 && E <= 1024, "router_select: E=%d out of range (1..1024)", E);
+  CSMOE_CHECK_ARG(K > 0 && K <= E && K <= 64, "router_select: K=%d out of range (1..min(E,64))", K);
+  CSMOE_CHECK_ARG(sel_mode >= 0 && sel_mode <= 3, "router_select: bad mode %d", sel_mode);
+  CSMOE_CHECK_ARG(scores && idx && w, "router_select: null pointer");
+  return k_router_select(scores, dtype, T, E, K, sel_mode, round_sum_bf16, softmax, idx, w, (hipStream_t)stream);
+}
+
+int csmoe_router_select_bwd(const void* scores, int dtype, int T, int E, int K, int sel_mode, int round_sum_bf16,
+                            const float* softmax, const int32_t* idx, const float* w, const float* dw, const float* dsoftmax,
+                            void* dscores, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype), "router_select_bwd: bad dtype %d", dtype);
+  CSMOE_CHECK_ARG(T >= 0 && E > 0 && E <= 1024 && K > 0 && K <= E && K <= 64, "router_select_bwd: bad shape");
+  CSMOE_CHECK_ARG(sel_mode >= 0 && sel_mode <= 3, "router_select_bwd: bad mode %d", sel_mode);
+  CSMOE_CHECK_ARG(scores && idx && w && dscores, "router_select_bwd: null pointer");
+  CSMOE_CHECK_ARG(softmax || (sel_mode != CSMOE_SEL_SOFTMAX && !dsoftmax), "router_select_bwd: softmax required");
+  return k_router_select_bwd(scores, dtype, T, E, K, sel_mode, round_sum_bf16, softmax, idx, w, dw, dsoftmax, dscores,
+                             (hipStream_t)stream);
+}
+
+int64_t csmoe_bin_workspace_bytes(int n, int E) { return k_bin_workspace_bytes(n, E); }
+
+int csmoe_bin_tokens(const int32_t* idx, int n, int E, int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* slot_of,
+                     void* workspace, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(n >= 0 && E > 0 && E <= 8192, "bin_tokens: bad n=%d E=%d", n, E);
+  CSMOE_CHECK_ARG(counts && offsets && workspace && (n == 0 || (idx && perm && slot_of)), "bin_tokens: null pointer");
+  return k_bin_tokens(idx, n, E, counts, offsets, perm, slot_of, workspace, (hipStream_t)stream);
+}
+
+int csmoe_dispatch_rows(const void* x, const int32_t* perm, int K, void* xs, int n, int D, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && n >= 0 && D > 0, "dispatch_rows: bad arguments");
+  CSMOE_CHECK_ARG(n == 0 || (x && perm && xs), "dispatch_rows: null pointer");
+  int row_bytes = D * esize(dtype);
+  // 16-B vector path needs 16-B aligned rows; otherwise the kernel copies 2 bytes at a time
+  int vec_ok = ((((uintptr_t)x | (uintptr_t)xs) & 15) == 0 && (row_bytes & 15) == 0) ? 1 : 0;
+  return k_dispatch_rows(x, perm, K, xs, n, row_bytes, vec_ok, (hipStream_t)stream);
+}
+
+int csmoe_dispatch_rows_bwd(const void* dxs, const int32_t* slot_of, int K, const void* add, void* dx, int T, int D, int dtype,
+                            csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && K <= 64 && T >= 0 && D > 0, "dispatch_rows_bwd: bad arguments");
+  CSMOE_CHECK_ARG(T == 0 || (dxs && slot_of && dx), "dispatch_rows_bwd: null pointer");
+  return k_combine(dxs, slot_of, nullptr, nullptr, nullptr, add, dx, T, K, D, dtype, CSMOE_COMBINE_DOT, (hipStream_t)stream);
+}
+
+int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias, void* out, int T,
+                  int K, int D, int dtype, int mode, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && K <= 64 && T >= 0 && D > 0, "combine: bad arguments (K<=64)");
+  CSMOE_CHECK_ARG(mode >= 0 && mode <= 2, "combine: bad mode %d", mode);
+  CSMOE_CHECK_ARG(T == 0 || (y && slot_of && w && out), "combine: null pointer");
+  CSMOE_CHECK_ARG(mode == CSMOE_COMBINE_DOT || idx, "combine: idx required for the sequential rounding rule");
+  return k_combine(y, slot_of, idx, w, obias, nullptr, out, T, K, D, dtype, mode, (hipStream_t)stream);
+}
+
+int csmoe_combine_bwd(const void* dout, const void* y, const int32_t* perm, const int32_t* slot_of, const float* w, void* dy,
+                      float* dw, int T, int K, int D, int dtype, csmoe_stream_t stream) {
+  (void)slot_of;
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && T >= 0 && D > 0, "combine_bwd: bad arguments");
+  CSMOE_CHECK_ARG(T == 0 || (dout && perm && dy), "combine_bwd: null pointer");
+  return k_combine_bwd(dout, y, perm, w, dy, dw, T * K, K, D, dtype, (hipStream_t)stream);
+}
+
+int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                       const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                       const void* aux, int64_t ldc, int epilogue, int act, int dtype, int force_generic,
+                       csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype), "grouped_gemm: bad dtype %d", dtype);
+  CSMOE_CHECK_ARG(E > 0 && M >= 0 && N > 0 && Kd > 0, "grouped_gemm: bad shape E=%d M=%d N=%d Kd=%d", E, M, N, Kd);
+  CSMOE_CHECK_ARG(b_layout == CSMOE_B_NK || b_layout == CSMOE_B_KN, "grouped_gemm: bad B layout %d", b_layout);
+  CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && act >= 0 && act <= 4, "grouped_gemm: bad epilogue/act");
+  CSMOE_CHECK_ARG(b_ptrs && offsets && (M == 0 || (A && C)), "grouped_gemm: null pointer");
+  CSMOE_CHECK_ARG(epilogue != CSMOE_EPI_ACTGRAD || aux, "grouped_gemm: ACTGRAD epilogue needs aux");
+  CSMOE_CHECK_ARG(lda >= Kd && ldc >= N && ldb >= (b_layout == CSMOE_B_NK ? Kd : N), "grouped_gemm: leading dimension too small");
+  if (M == 0) return CSMOE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C))
+    return gg_fast_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
+                            nullptr, nullptr, st);
+  return gg_generic_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
+                             dtype, nullptr, nullptr, st);
+}
+
+int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, int64_t ldb, const void* bias, int M, int N,
+                     int Kd, void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, int dtype,
+                     int force_generic, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && M >= 0 && N > 0 && Kd > 0, "dense_gemm: bad arguments");
+  CSMOE_CHECK_ARG(M == 0 || (A && B && C), "dense_gemm: null pointer");
+  CSMOE_CHECK_ARG(epilogue != CSMOE_EPI_ACTGRAD || aux, "dense_gemm: ACTGRAD epilogue needs aux");
+  if (M == 0) return CSMOE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C))
+    return gg_fast_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B,
+                            bias, st);
+  return gg_generic_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act,
+                             dtype, B, bias, st);
+}
+
+int csmoe_grouped_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int M, int Na,
+                        int Nb, void* const* c_ptrs, int64_t ldc, int dtype, int out_dtype, int accumulate, int force_generic,
+                        csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && dtype_ok(out_dtype), "grouped_wgrad: bad dtype");
+  CSMOE_CHECK_ARG(E > 0 && M >= 0 && Na > 0 && Nb > 0, "grouped_wgrad: bad shape");
+  CSMOE_CHECK_ARG(c_ptrs && offsets && (M == 0 || (A && B)), "grouped_wgrad: null pointer");
+  CSMOE_CHECK_ARG(lda >= Na && ldb >= Nb && ldc >= Nb, "grouped_wgrad: leading dimension too small");
+  CSMOE_CHECK_ARG(!(dtype == CSMOE_F32 && out_dtype != CSMOE_F32), "grouped_wgrad: fp32 inputs need fp32 output");
+  hipStream_t st = (hipStream_t)stream;
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_wgrad_ok(lda, ldb, ldc, M, Na, Nb, A, B))
+    return gg_fast_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, out_dtype, accumulate, 0, nullptr, st);
+  return gg_generic_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, dtype, out_dtype, accumulate, 0, nullptr, st);
+}
+
+int csmoe_dense_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int Na, int Nb, void* C, int64_t ldc,
+                      int dtype, int out_dtype, int accumulate, int force_generic, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && dtype_ok(out_dtype) && M >= 0 && Na > 0 && Nb > 0, "dense_wgrad: bad arguments");
+  CSMOE_CHECK_ARG(C && (M == 0 || (A && B)), "dense_wgrad: null pointer");
+  CSMOE_CHECK_ARG(!(dtype == CSMOE_F32 && out_dtype != CSMOE_F32), "dense_wgrad: fp32 inputs need fp32 output");
+  hipStream_t st = (hipStream_t)stream;
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_wgrad_ok(lda, ldb, ldc, M, Na, Nb, A, B))
+    return gg_fast_wgrad(A, lda, B, ldb, nullptr, 1, Na, Nb, nullptr, ldc, out_dtype, accumulate, M, C, st);
+  return gg_generic_wgrad(A, lda, B, ldb, nullptr, 1, Na, Nb, nullptr, ldc, dtype, out_dtype, accumulate, M, C, st);
+}
+
+int csmoe_grouped_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int N, void* const* out_ptrs, int dtype,
+                         int out_dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && dtype_ok(out_dtype) && E > 0 && N > 0, "grouped_colsum: bad arguments");
+  CSMOE_CHECK_ARG(G && offsets && out_ptrs, "grouped_colsum: null pointer");
+  return k_colsum(G, ldg, offsets, E, 0, N, out_ptrs, nullptr, dtype, out_dtype, (hipStream_t)stream);
+}
+
+int csmoe_dense_colsum(const void* G, int64_t ldg, int M, int N, void* out, int dtype, int out_dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && dtype_ok(out_dtype) && M >= 0 && N > 0, "dense_colsum: bad arguments");
+  CSMOE_CHECK_ARG(out && (M == 0 || G), "dense_colsum: null pointer");
+  return k_colsum(G, ldg, nullptr, 1, M, N, nullptr, out, dtype, out_dtype, (hipStream_t)stream);
+}
+
+int csmoe_softplus_mean(const void* y, void* aff, int R, int D, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && R >= 0 && D > 0, "softplus_mean: bad arguments");
+  CSMOE_CHECK_ARG(R == 0 || (y && aff), "softplus_mean: null pointer");
+  return k_softplus_mean(y, aff, R, D, dtype, (hipStream_t)stream);
+}
+
+int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype,
+                            csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && R >= 0 && D > 0, "softplus_mean_bwd: bad arguments");
+  CSMOE_CHECK_ARG(R == 0 || (y && daff && dy), "softplus_mean_bwd: null pointer");
+  return k_softplus_mean_bwd(y, daff, dy_add, dy, R, D, dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Shared device/host helpers for the CompeteSMoE MI355X (gfx950) kernels.
+// CDNA4 only: 64-wide wavefronts, MFMA, LDS-DMA.  No CUDA compatibility layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/csmoe.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+#define CSMOE_WAVE 64
+
+// ------------------------------------------------------------------ error plumbing (host)
+void csmoe_set_error(const char* fmt, ...);
+#define CSMOE_CHECK_ARG(cond, ...)                      \
+  do {                                                  \
+    if (!(cond)) {                                      \
+      csmoe_set_error(__VA_ARGS__);                     \
+      return CSMOE_ERR_INVALID;                         \
+    }                                                   \
+  } while (0)
+#define CSMOE_CHECK_LAUNCH(name)                                                     \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      csmoe_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return CSMOE_ERR_LAUNCH;                                                       \
+    }                                                                                \
+  } while (0)
+
+// ------------------------------------------------------------------ dtype helpers (device)
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float rnd(float v) { return v; }
+};
+template <> struct DT<bf16> {
+  static __device__ __forceinline__ float ld(const bf16* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(bf16* p, float v) { *p = (bf16)v; }
+  static __device__ __forceinline__ float rnd(float v) { return (float)(bf16)v; }
+};
+
+// ------------------------------------------------------------------ activations (fp32 math)
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case CSMOE_ACT_RELU: return x > 0.f ? x : 0.f;
+    case CSMOE_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    case CSMOE_ACT_GELU_TANH: {
+      const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
+      float inner = k0 * (x + k1 * x * x * x);
+      return 0.5f * x * (1.f + tanhf(inner));
+    }
+    case CSMOE_ACT_SILU: return x / (1.f + __expf(-x));
+    default: return x;
+  }
+}
+// d act(x) / dx
+__device__ __forceinline__ float act_bwd(float x, int act) {
+  switch (act) {
+    case CSMOE_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case CSMOE_ACT_GELU: {
+      float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+      float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case CSMOE_ACT_GELU_TANH: {
+      const float k0 = 0.79788456080286535588f, k1 = 0.044715f;
+      float x2 = x * x;
+      float inner = k0 * (x + k1 * x * x2);
+      float t = tanhf(inner);
+      float dinner = k0 * (1.f + 3.f * k1 * x2);
+      return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * dinner;
+    }
+    case CSMOE_ACT_SILU: {
+      float s = 1.f / (1.f + __expf(-x));
+      return s * (1.f + x * (1.f - s));
+    }
+    default: return 1.f;
+  }
+}
+
+// ------------------------------------------------------------------ wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id (guide T1): blocks id and id+8 share an XCD, so give
+// every XCD one contiguous chunk of the virtual tile order.  n = number of live tiles.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  int q = n >> 3, r = n & 7, x = id & 7;
+  int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (id >> 3);
+}

@@ -1,0 +1,632 @@
+// HBM-bound kernels of the sparse-MoE hot path for gfx950: router selection, token binning, dispatch / combine,
+// bias-gradient column sums and the competition affinity reduction.  One wave (64 lanes) per token row, 16-byte
+// vector accesses, wavefront shuffles for the row reductions / arg-max.
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+// =====================================================================================================================
+// Router selection (moe_model/model/moe/moe.py:113-132, smoe.py:44, competesmoe.py:246-255;
+//                   moe_pretrain_model/layers/moe/deepseekv2.py:140-142, deepseekv3.py:147-151)
+// One wave per token; lane l holds scores l, l+64, ... (VPL values per lane, E <= 64*VPL).
+// =====================================================================================================================
+__device__ __forceinline__ float round_dt(float v, int dtype) { return dtype == CSMOE_BF16 ? (float)(bf16)v : v; }
+__device__ __forceinline__ float load_score(const void* p, int64_t i, int dtype) {
+  return dtype == CSMOE_BF16 ? (float)((const bf16*)p)[i] : ((const float*)p)[i];
+}
+__device__ __forceinline__ void store_score(void* p, int64_t i, float v, int dtype) {
+  if (dtype == CSMOE_BF16) ((bf16*)p)[i] = (bf16)v; else ((float*)p)[i] = v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// wave arg-max with lowest-index tie break over (val, idx) pairs held one per lane
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+template <int VPL>
+__global__ void __launch_bounds__(256) router_select_kernel(const void* scores, int dtype, int T, int E, int K, int mode,
+                                                            int round_sum_bf16, float* softmax, int32_t* idx, float* w) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int64_t base = (int64_t)t * E;
+  float s[VPL], key[VPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    int e = lane + 64 * v;
+    s[v] = e < E ? load_score(scores, base + e, dtype) : -INFINITY;
+    mx = fmaxf(mx, s[v]);
+  }
+  mx = wave_max(mx);
+  // fp32 softmax of the scores (always produced when requested: losses need it)
+  float ex[VPL], sum = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    int e = lane + 64 * v;
+    ex[v] = e < E ? expf(s[v] - mx) : 0.f;
+    sum += ex[v];
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    int e = lane + 64 * v;
+    float p = ex[v] / sum;
+    if (softmax && e < E) softmax[base + e] = p;
+    if (mode == CSMOE_SEL_SOFTMAX) key[v] = p;
+    else if (mode == CSMOE_SEL_SIGMOID) key[v] = round_dt(sigmoidf_(s[v]), dtype);
+    else key[v] = s[v];
+    if (e >= E) key[v] = -INFINITY;
+  }
+  // K rounds of wave arg-max, removing the winner each round
+  float vsum = 0.f;
+  float myv = 0.f;    // lane k keeps the k-th value
+  int myi = 0;
+  for (int k = 0; k < K; ++k) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      int e = lane + 64 * v;
+      if (key[v] > bv || (key[v] == bv && e < bi)) { bv = key[v]; bi = e; }
+    }
+    wave_argmax(bv, bi);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+      if (lane + 64 * v == bi) key[v] = -INFINITY;
+    if (lane == k) { myv = bv; myi = bi; }
+    vsum += bv;   // summed in k order, identical in every lane
+  }
+  if (mode == CSMOE_SEL_TOPK_SOFTMAX) {
+    // softmax over the K selected logits (fp32)
+    float top = __shfl(myv, 0, 64);
+    float ek = lane < K ? expf(myv - top) : 0.f;
+    float es = wave_sum(ek);
+    if (lane < K) { w[(int64_t)t * K + lane] = ek / es; idx[(int64_t)t * K + lane] = myi; }
+    return;
+  }
+  float denom, wk;
+  if (mode == CSMOE_SEL_SOFTMAX) {
+    denom = round_sum_bf16 ? (float)(bf16)vsum : vsum;
+    wk = myv / denom;
+  } else if (mode == CSMOE_SEL_RAW) {
+    denom = round_dt(vsum, dtype);
+    wk = round_dt(myv / denom, dtype);
+  } else {  // SIGMOID
+    denom = round_dt(vsum, dtype) + 1e-20f;
+    wk = round_dt(myv / denom, dtype);
+  }
+  if (lane < K) { w[(int64_t)t * K + lane] = wk; idx[(int64_t)t * K + lane] = myi; }
+}
+
+template <int VPL>
+__global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scores, int dtype, int T, int E, int K, int mode,
+                                                                int round_sum_bf16, const float* softmax, const int32_t* idx,
+                                                                const float* w, const float* dw, const float* dsoftmax,
+                                                                void* dscores) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int64_t base = (int64_t)t * E;
+  // lane k (< K) holds slot k
+  int myi = -1;
+  float mydw = 0.f, myw = 0.f, myv = 0.f;
+  if (lane < K) {
+    myi = idx[(int64_t)t * K + lane];
+    mydw = dw ? dw[(int64_t)t * K + lane] : 0.f;
+    myw = w[(int64_t)t * K + lane];
+    if (mode == CSMOE_SEL_SOFTMAX) myv = softmax[base + myi];
+    else if (mode == CSMOE_SEL_SIGMOID) myv = round_dt(sigmoidf_(load_score(scores, base + myi, dtype)), dtype);
+    else myv = load_score(scores, base + myi, dtype);
+  }
+  float dv = 0.f;   // gradient w.r.t. the selected value of slot `lane`
+  if (mode == CSMOE_SEL_TOPK_SOFTMAX) {
+    float dot = wave_sum(mydw * myw);
+    dv = myw * (mydw - dot);
+  } else {
+    float ssum = wave_sum(myv);
+    float denom;
+    if (mode == CSMOE_SEL_SOFTMAX) denom = round_sum_bf16 ? (float)(bf16)ssum : ssum;
+    else if (mode == CSMOE_SEL_RAW) denom = round_dt(ssum, dtype);
+    else denom = round_dt(ssum, dtype) + 1e-20f;
+    float dot = wave_sum(mydw * myv);
+    dv = mydw / denom - dot / (denom * denom);
+    if (mode == CSMOE_SEL_SIGMOID) dv *= myv * (1.f - myv);
+  }
+  // scatter dv to the expert positions; softmax-path gradient
+  float g[VPL], p[VPL];
+  float inner = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    int e = lane + 64 * v;
+    p[v] = (softmax && e < E) ? softmax[base + e] : 0.f;
+    g[v] = (dsoftmax && e < E) ? dsoftmax[base + e] : 0.f;   // d loss / d softmax
+  }
+  float direct[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) direct[v] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    int ei = __shfl(myi, k, 64);
+    float d = __shfl(dv, k, 64);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+      if (lane + 64 * v == ei) {
+        if (mode == CSMOE_SEL_SOFTMAX) g[v] += d; else direct[v] += d;
+      }
+  }
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) inner += g[v] * p[v];
+  inner = wave_sum(inner);
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    int e = lane + 64 * v;
+    if (e < E) store_score(dscores, base + e, p[v] * (g[v] - inner) + direct[v], dtype);
+  }
+}
+
+// =====================================================================================================================
+// Binning: stable counting sort of expert ids (replaces cvmm_prepare_sel2's sort, cvmm.py:580-593, and the E torch.where
+// scans of compute_moe, moe.py:189-191).  1024 ids per workgroup; ranks inside a wave by ballot "match-any".
+// =====================================================================================================================
+constexpr int BIN_CHUNK = 1024;
+
+__global__ void __launch_bounds__(256) bin_hist_kernel(const int32_t* idx, int n, int E, int32_t* block_hist) {
+  extern __shared__ int32_t h[];
+  for (int i = threadIdx.x; i < E; i += 256) h[i] = 0;
+  __syncthreads();
+  int base = blockIdx.x * BIN_CHUNK;
+  for (int i = threadIdx.x; i < BIN_CHUNK; i += 256) {
+    int j = base + i;
+    if (j < n) {
+      int e = idx[j];
+      if (e >= 0 && e < E) atomicAdd(&h[e], 1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < E; i += 256) block_hist[(int64_t)blockIdx.x * E + i] = h[i];
+}
+
+__global__ void __launch_bounds__(1024) bin_scan_kernel(const int32_t* block_hist, int nb, int E, int32_t* counts,
+                                                        int32_t* offsets, int32_t* block_base) {
+  extern __shared__ int32_t c[];   // counts, then exclusive offsets
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    int s = 0;
+    for (int b = 0; b < nb; ++b) s += block_hist[(int64_t)b * E + e];
+    c[e] = s;
+    counts[e] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int e = 0; e < E; ++e) { int v = c[e]; c[e] = run; offsets[e] = run; run += v; }
+    offsets[E] = run;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    int run = c[e];
+    for (int b = 0; b < nb; ++b) {
+      block_base[(int64_t)b * E + e] = run;
+      run += block_hist[(int64_t)b * E + e];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) bin_scatter_kernel(const int32_t* idx, int n, int E, int ebits,
+                                                          const int32_t* block_base, int32_t* perm, int32_t* slot_of) {
+  extern __shared__ int32_t sm[];
+  int32_t* running = sm;          // [E]
+  int32_t* wcnt = sm + E;         // [4][E]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < E; i += 256) running[i] = block_base[(int64_t)blockIdx.x * E + i];
+  for (int i = threadIdx.x; i < 4 * E; i += 256) wcnt[i] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * BIN_CHUNK;
+  for (int round = 0; round < BIN_CHUNK / 256; ++round) {
+    int j = base + round * 256 + threadIdx.x;
+    bool valid = j < n;
+    int e = valid ? idx[j] : -1;
+    valid = valid && e >= 0 && e < E;
+    // lanes of this wave holding the same expert
+    unsigned long long mask = __ballot(valid);
+    for (int b = 0; b < ebits; ++b) {
+      unsigned long long bm = __ballot((e >> b) & 1);
+      mask &= ((e >> b) & 1) ? bm : ~bm;
+    }
+    int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    int cnt = __popcll(mask);
+    if (valid && rank == cnt - 1) wcnt[wave * E + e] = cnt;   // one writer per (wave, expert)
+    __syncthreads();
+    if (valid) {
+      int pos = running[e] + rank;
+      for (int w2 = 0; w2 < wave; ++w2) pos += wcnt[w2 * E + e];
+      perm[pos] = j;
+      slot_of[j] = pos;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < E; i += 256) {
+      running[i] += wcnt[i] + wcnt[E + i] + wcnt[2 * E + i] + wcnt[3 * E + i];
+      wcnt[i] = 0; wcnt[E + i] = 0; wcnt[2 * E + i] = 0; wcnt[3 * E + i] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+// =====================================================================================================================
+// Dispatch (gather rows into the binned row space) -- moe.py:201 `x[batch_idx, token_idx]`, cvmm.py:114-119
+// One wave per destination row, 16 B per lane per access, rows visited with a grid-stride.
+// =====================================================================================================================
+__global__ void __launch_bounds__(256) dispatch_rows_kernel(const char* x, const int32_t* perm, int K, char* xs, int n,
+                                                            int row_bytes, int vec_ok) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  const int nv = vec_ok ? (row_bytes >> 4) : 0;
+  for (int m = wave_g; m < n; m += nw) {
+    const int t = perm[m] / K;
+    const i32x4* src = (const i32x4*)(x + (int64_t)t * row_bytes);
+    i32x4* dst = (i32x4*)(xs + (int64_t)m * row_bytes);
+    for (int i = lane; i < nv; i += 64) dst[i] = src[i];
+    // tail (row_bytes not a multiple of 16): 2-byte granularity
+    for (int b = (nv << 4) + lane * 2; b < row_bytes; b += 128)
+      *(short*)((char*)dst + b) = *(const short*)((const char*)src + b);
+  }
+}
+
+// =====================================================================================================================
+// Combine  (moe.py:204 / cvmm.py:481-483) and the dispatch backward gather-sum (cvmm.py:544-545)
+// =====================================================================================================================
+constexpr int MAXK = 64;   // one lane per selected slot
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t* slot_of, const int32_t* idx, const float* w,
+                                                      const T* obias, const T* add, T* out, int Tn, int K, int D, int mode) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int t = wave_g; t < Tn; t += nw) {
+    // lane k (< K) holds slot k; visit order is found with ballots so nothing is runtime-indexed (no scratch)
+    int myslot = 0, mye = 0, rank = 0;
+    float myw = 1.f;
+    if (lane < K) {
+      myslot = slot_of[(int64_t)t * K + lane];
+      if (w) myw = w[(int64_t)t * K + lane];
+      if (idx) mye = idx[(int64_t)t * K + lane];
+    }
+    if (mode != CSMOE_COMBINE_DOT && idx) {
+      // experts in ascending index order (the reference loops `for i, expert in enumerate(self.experts)`)
+      for (int j = 0; j < K; ++j) {
+        int ej = __shfl(mye, j, 64);
+        rank += (ej < mye || (ej == mye && j < lane)) ? 1 : 0;
+      }
+    } else {
+      rank = lane;
+    }
+    for (int d0 = lane * VEC; d0 < D; d0 += 64 * VEC) {
+      float acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+      for (int kk = 0; kk < K; ++kk) {
+        const int src = __ffsll((unsigned long long)__ballot(lane < K && rank == kk)) - 1;
+        const int sl = __shfl(myslot, src, 64);
+        const float wv = __shfl(myw, src, 64);
+        const T* row = y + (int64_t)sl * D + d0;
+        float yv[VEC];
+        if constexpr (VEC == 8) {
+          bf16x8 r8 = *(const bf16x8*)row;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) yv[v] = (float)r8[v];
+        } else if constexpr (VEC == 4) {
+          f32x4 r4 = *(const f32x4*)row;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) yv[v] = r4[v];
+        } else {
+          yv[0] = DT<T>::ld(row);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          if (mode == CSMOE_COMBINE_DOT) {
+            acc[v] = fmaf(wv, yv[v], acc[v]);
+          } else {
+            float prod = __fmul_rn(wv, yv[v]);
+            if (mode == CSMOE_COMBINE_SEQ_RW) prod = DT<T>::rnd(prod);
+            acc[v] = DT<T>::rnd(__fadd_rn(acc[v], prod));
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float r = acc[v];
+        if (mode == CSMOE_COMBINE_DOT) r = DT<T>::rnd(r);
+        if (obias) r = DT<T>::rnd(r + DT<T>::ld(obias + d0 + v));
+        if (add) r = DT<T>::rnd(r + DT<T>::ld(add + (int64_t)t * D + d0 + v));
+        acc[v] = r;
+      }
+      T* o = out + (int64_t)t * D + d0;
+      if constexpr (VEC == 8) {
+        bf16x8 o8;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o8[v] = (bf16)acc[v];
+        *(bf16x8*)o = o8;
+      } else if constexpr (VEC == 4) {
+        *(f32x4*)o = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      } else {
+        DT<T>::st(o, acc[0]);
+      }
+    }
+  }
+}
+
+// combine backward: one wave per binned row m
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) combine_bwd_kernel(const T* dout, const T* y, const int32_t* perm, const float* w, T* dy,
+                                                          float* dw, int n, int K, int D) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int m = wave_g; m < n; m += nw) {
+    const int flat = perm[m];
+    const int t = flat / K;
+    const float wk = w ? w[flat] : 1.f;
+    float dot = 0.f;
+    for (int d0 = lane * VEC; d0 < D; d0 += 64 * VEC) {
+      const T* g = dout + (int64_t)t * D + d0;
+      float gv[VEC], yv[VEC];
+      if constexpr (VEC == 8) {
+        bf16x8 g8 = *(const bf16x8*)g;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) gv[v] = (float)g8[v];
+        if (y) {
+          bf16x8 y8 = *(const bf16x8*)(y + (int64_t)m * D + d0);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) yv[v] = (float)y8[v];
+        }
+        bf16x8 o8;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o8[v] = (bf16)(gv[v] * wk);
+        *(bf16x8*)(dy + (int64_t)m * D + d0) = o8;
+      } else if constexpr (VEC == 4) {
+        f32x4 g4 = *(const f32x4*)g;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) gv[v] = g4[v];
+        if (y) {
+          f32x4 y4 = *(const f32x4*)(y + (int64_t)m * D + d0);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) yv[v] = y4[v];
+        }
+        *(f32x4*)(dy + (int64_t)m * D + d0) = f32x4{gv[0] * wk, gv[1] * wk, gv[2] * wk, gv[3] * wk};
+      } else {
+        gv[0] = DT<T>::ld(g);
+        if (y) yv[0] = DT<T>::ld(y + (int64_t)m * D + d0);
+        DT<T>::st(dy + (int64_t)m * D + d0, gv[0] * wk);
+      }
+      if (y) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dot = fmaf(gv[v], yv[v], dot);
+      }
+    }
+    if (y && dw) {
+      dot = wave_sum(dot);
+      if (lane == 0) dw[flat] = dot;
+    }
+  }
+}
+
+// =====================================================================================================================
+// Per-expert column sums (bias gradients).  grid = (ceil(N/256), E); 4 waves split the rows, lane = 4 columns.
+// =====================================================================================================================
+template <typename T, typename TOut>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* G, int64_t ldg, const int32_t* offsets, int single_M, int N,
+                                                     void* const* out_ptrs, void* single_out) {
+  __shared__ float part[4][256];
+  const int e = blockIdx.y;
+  const int r0 = offsets ? offsets[e] : 0, r1 = offsets ? offsets[e + 1] : single_M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 256 + lane * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0 + wave; r < r1; r += 4) {
+    const T* row = G + (int64_t)r * ldg + c0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < N) s[j] += DT<T>::ld(row + j);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) part[wave][lane * 4 + j] = s[j];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < N) {
+    float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    TOut* o = (TOut*)(out_ptrs ? out_ptrs[e] : single_out);
+    DT<TOut>::st(o + c, v);
+  }
+}
+
+// =====================================================================================================================
+// Competition affinity: aff[r] = mean_d softplus(y[r,d])  (competesmoe.py:242) and its backward
+// =====================================================================================================================
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) softplus_mean_kernel(const T* y, T* aff, int R, int D) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int r = wave_g; r < R; r += nw) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += DT<T>::rnd(softplusf_(DT<T>::ld(y + (int64_t)r * D + d)));
+    s = wave_sum(s);
+    if (lane == 0) DT<T>::st(aff + r, s / (float)D);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) softplus_mean_bwd_kernel(const T* y, const T* daff, const T* dy_add, T* dy, int R, int D) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int r = wave_g; r < R; r += nw) {
+    const float g = DT<T>::rnd(DT<T>::ld(daff + r) / (float)D);
+    for (int d = lane; d < D; d += 64) {
+      const int64_t o = (int64_t)r * D + d;
+      float x = DT<T>::ld(y + o);
+      float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+      float v = DT<T>::rnd(g * sg);
+      if (dy_add) v = DT<T>::rnd(v + DT<T>::ld(dy_add + o));
+      DT<T>::st(dy + o, v);
+    }
+  }
+}
+
+inline int stride_grid(int rows) { return std::max(1, std::min((rows + 3) / 4, 4096)); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host launchers
+#define SEL_DISPATCH(KERNEL, ...)                                                                 \
+  do {                                                                                            \
+    int vpl = (E + 63) / 64;                                                                      \
+    dim3 grid((T + 3) / 4), block(256);                                                           \
+    if (vpl <= 1) hipLaunchKernelGGL((KERNEL<1>), grid, block, 0, st, __VA_ARGS__);               \
+    else if (vpl <= 2) hipLaunchKernelGGL((KERNEL<2>), grid, block, 0, st, __VA_ARGS__);          \
+    else if (vpl <= 4) hipLaunchKernelGGL((KERNEL<4>), grid, block, 0, st, __VA_ARGS__);          \
+    else if (vpl <= 8) hipLaunchKernelGGL((KERNEL<8>), grid, block, 0, st, __VA_ARGS__);          \
+    else hipLaunchKernelGGL((KERNEL<16>), grid, block, 0, st, __VA_ARGS__);                       \
+  } while (0)
+
+int k_router_select(const void* scores, int dtype, int T, int E, int K, int mode, int round_sum_bf16, float* softmax,
+                    int32_t* idx, float* w, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  SEL_DISPATCH(router_select_kernel, scores, dtype, T, E, K, mode, round_sum_bf16, softmax, idx, w);
+  CSMOE_CHECK_LAUNCH("router_select");
+  return CSMOE_OK;
+}
+
+int k_router_select_bwd(const void* scores, int dtype, int T, int E, int K, int mode, int round_sum_bf16, const float* softmax,
+                        const int32_t* idx, const float* w, const float* dw, const float* dsoftmax, void* dscores,
+                        hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  SEL_DISPATCH(router_select_bwd_kernel, scores, dtype, T, E, K, mode, round_sum_bf16, softmax, idx, w, dw, dsoftmax, dscores);
+  CSMOE_CHECK_LAUNCH("router_select_bwd");
+  return CSMOE_OK;
+}
+
+int64_t k_bin_workspace_bytes(int n, int E) {
+  int64_t nb = (n + BIN_CHUNK - 1) / BIN_CHUNK;
+  return 2 * nb * (int64_t)E * 4 + 64;
+}
+
+int k_bin_tokens(const int32_t* idx, int n, int E, int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* slot_of,
+                 void* workspace, hipStream_t st) {
+  int nb = (n + BIN_CHUNK - 1) / BIN_CHUNK;
+  if (nb == 0) nb = 1;
+  int32_t* block_hist = (int32_t*)workspace;
+  int32_t* block_base = block_hist + (int64_t)nb * E;
+  int ebits = 0;
+  while ((1 << ebits) < E) ++ebits;
+  hipLaunchKernelGGL(bin_hist_kernel, dim3(nb), dim3(256), E * 4, st, idx, n, E, block_hist);
+  hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), E * 4, st, block_hist, nb, E, counts, offsets, block_base);
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nb), dim3(256), 5 * E * 4, st, idx, n, E, ebits, block_base, perm, slot_of);
+  CSMOE_CHECK_LAUNCH("bin_tokens");
+  return CSMOE_OK;
+}
+
+int k_dispatch_rows(const void* x, const int32_t* perm, int K, void* xs, int n, int row_bytes, int vec_ok, hipStream_t st) {
+  if (n == 0) return CSMOE_OK;
+  hipLaunchKernelGGL(dispatch_rows_kernel, dim3(stride_grid(n)), dim3(256), 0, st, (const char*)x, perm, K, (char*)xs, n,
+                     row_bytes, vec_ok);
+  CSMOE_CHECK_LAUNCH("dispatch_rows");
+  return CSMOE_OK;
+}
+
+int k_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias, const void* add,
+              void* out, int T, int K, int D, int dtype, int mode, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  dim3 grid(stride_grid(T)), block(256);
+  const bool al = (((uintptr_t)y | (uintptr_t)out | (uintptr_t)obias | (uintptr_t)add) & 15) == 0;
+  if (dtype == CSMOE_BF16) {
+    if (D % 8 == 0 && al)
+      hipLaunchKernelGGL((combine_kernel<bf16, 8>), grid, block, 0, st, (const bf16*)y, slot_of, idx, w, (const bf16*)obias,
+                         (const bf16*)add, (bf16*)out, T, K, D, mode);
+    else
+      hipLaunchKernelGGL((combine_kernel<bf16, 1>), grid, block, 0, st, (const bf16*)y, slot_of, idx, w, (const bf16*)obias,
+                         (const bf16*)add, (bf16*)out, T, K, D, mode);
+  } else {
+    if (D % 4 == 0 && al)
+      hipLaunchKernelGGL((combine_kernel<float, 4>), grid, block, 0, st, (const float*)y, slot_of, idx, w, (const float*)obias,
+                         (const float*)add, (float*)out, T, K, D, mode);
+    else
+      hipLaunchKernelGGL((combine_kernel<float, 1>), grid, block, 0, st, (const float*)y, slot_of, idx, w, (const float*)obias,
+                         (const float*)add, (float*)out, T, K, D, mode);
+  }
+  CSMOE_CHECK_LAUNCH("combine");
+  return CSMOE_OK;
+}
+
+int k_combine_bwd(const void* dout, const void* y, const int32_t* perm, const float* w, void* dy, float* dw, int n, int K, int D,
+                  int dtype, hipStream_t st) {
+  if (n == 0) return CSMOE_OK;
+  dim3 grid(stride_grid(n)), block(256);
+  const bool al = (((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0;
+  if (dtype == CSMOE_BF16) {
+    if (D % 8 == 0 && al)
+      hipLaunchKernelGGL((combine_bwd_kernel<bf16, 8>), grid, block, 0, st, (const bf16*)dout, (const bf16*)y, perm, w, (bf16*)dy,
+                         dw, n, K, D);
+    else
+      hipLaunchKernelGGL((combine_bwd_kernel<bf16, 1>), grid, block, 0, st, (const bf16*)dout, (const bf16*)y, perm, w, (bf16*)dy,
+                         dw, n, K, D);
+  } else {
+    if (D % 4 == 0 && al)
+      hipLaunchKernelGGL((combine_bwd_kernel<float, 4>), grid, block, 0, st, (const float*)dout, (const float*)y, perm, w,
+                         (float*)dy, dw, n, K, D);
+    else
+      hipLaunchKernelGGL((combine_bwd_kernel<float, 1>), grid, block, 0, st, (const float*)dout, (const float*)y, perm, w,
+                         (float*)dy, dw, n, K, D);
+  }
+  CSMOE_CHECK_LAUNCH("combine_bwd");
+  return CSMOE_OK;
+}
+
+int k_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int single_M, int N, void* const* out_ptrs,
+             void* single_out, int dtype, int out_dtype, hipStream_t st) {
+  if (N == 0 || E == 0) return CSMOE_OK;
+  dim3 grid((N + 255) / 256, E), block(256);
+  if (dtype == CSMOE_F32)
+    hipLaunchKernelGGL((colsum_kernel<float, float>), grid, block, 0, st, (const float*)G, ldg, offsets, single_M, N, out_ptrs,
+                       single_out);
+  else if (out_dtype == CSMOE_F32)
+    hipLaunchKernelGGL((colsum_kernel<bf16, float>), grid, block, 0, st, (const bf16*)G, ldg, offsets, single_M, N, out_ptrs,
+                       single_out);
+  else
+    hipLaunchKernelGGL((colsum_kernel<bf16, bf16>), grid, block, 0, st, (const bf16*)G, ldg, offsets, single_M, N, out_ptrs,
+                       single_out);
+  CSMOE_CHECK_LAUNCH("grouped_colsum");
+  return CSMOE_OK;
+}
+
+int k_softplus_mean(const void* y, void* aff, int R, int D, int dtype, hipStream_t st) {
+  if (R == 0) return CSMOE_OK;
+  if (dtype == CSMOE_BF16)
+    hipLaunchKernelGGL((softplus_mean_kernel<bf16>), dim3(stride_grid(R)), dim3(256), 0, st, (const bf16*)y, (bf16*)aff, R, D);
+  else
+    hipLaunchKernelGGL((softplus_mean_kernel<float>), dim3(stride_grid(R)), dim3(256), 0, st, (const float*)y, (float*)aff, R, D);
+  CSMOE_CHECK_LAUNCH("softplus_mean");
+  return CSMOE_OK;
+}
+
+int k_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype, hipStream_t st) {
+  if (R == 0) return CSMOE_OK;
+  if (dtype == CSMOE_BF16)
+    hipLaunchKernelGGL((softplus_mean_bwd_kernel<bf16>), dim3(stride_grid(R)), dim3(256), 0, st, (const bf16*)y, (const bf16*)daff,
+                       (const bf16*)dy_add, (bf16*)dy, R, D);
+  else
+    hipLaunchKernelGGL((softplus_mean_bwd_kernel<float>), dim3(stride_grid(R)), dim3(256), 0, st, (const float*)y,
+                       (const float*)daff, (const float*)dy_add, (float*)dy, R, D);
+  CSMOE_CHECK_LAUNCH("softplus_mean_bwd");
+  return CSMOE_OK;
+}

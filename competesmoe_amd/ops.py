@@ -1,0 +1,207 @@
+"""Thin tensor-level wrappers over the C ABI: allocate outputs with torch, pass raw device pointers and the
+current HIP stream.  No math happens here."""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+lib = L.lib
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.F32
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    raise ValueError(f"csmoe: unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("csmoe: tensors must live on the GPU (the HIP path has no CPU fallback)")
+
+
+def ptr_array(tensors: Sequence[Optional[torch.Tensor]], device) -> torch.Tensor:
+    """Device array of raw pointers (int64) -- the per-expert weight table handed to the grouped GEMM."""
+    return torch.tensor([0 if t is None else t.data_ptr() for t in tensors], dtype=torch.int64, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ router
+def gate_logits(x2: torch.Tensor, w_gate: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x2, w_gate)
+    T, D = x2.shape
+    E = w_gate.shape[0]
+    out = torch.empty(T, E, dtype=x2.dtype, device=x2.device)
+    L.check(lib.csmoe_gate_logits(x2.data_ptr(), w_gate.data_ptr(), out.data_ptr(), T, D, E, _dt(x2), _stream()), "gate_logits")
+    return out
+
+
+def router_select(scores: torch.Tensor, K: int, mode: int, round_sum_bf16: bool, want_softmax: bool = True):
+    _need_cuda(scores)
+    T, E = scores.shape
+    sm = torch.empty(T, E, dtype=torch.float32, device=scores.device) if want_softmax else None
+    idx = torch.empty(T, K, dtype=torch.int32, device=scores.device)
+    w = torch.empty(T, K, dtype=torch.float32, device=scores.device)
+    L.check(lib.csmoe_router_select(scores.data_ptr(), _dt(scores), T, E, K, mode, int(round_sum_bf16), _ptr(sm),
+                                    idx.data_ptr(), w.data_ptr(), _stream()), "router_select")
+    return sm, idx, w
+
+
+def router_select_bwd(scores, K, mode, round_sum_bf16, sm, idx, w, dw, dsm):
+    T, E = scores.shape
+    out = torch.empty_like(scores)
+    L.check(lib.csmoe_router_select_bwd(scores.data_ptr(), _dt(scores), T, E, K, mode, int(round_sum_bf16), _ptr(sm),
+                                        idx.data_ptr(), w.data_ptr(), _ptr(dw), _ptr(dsm), out.data_ptr(), _stream()),
+            "router_select_bwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ binning
+class Bins:
+    """Binned row space of one routing decision."""
+    __slots__ = ("counts", "offsets", "perm", "slot_of", "n", "E", "K")
+
+    def __init__(self, counts, offsets, perm, slot_of, n, E, K):
+        self.counts, self.offsets, self.perm, self.slot_of = counts, offsets, perm, slot_of
+        self.n, self.E, self.K = n, E, K
+
+
+def bin_tokens(idx: torch.Tensor, E: int) -> Bins:
+    _need_cuda(idx)
+    if idx.dtype != torch.int32:
+        raise ValueError("csmoe: expert indices must be int32")
+    idx = idx.contiguous()
+    n = idx.numel()
+    K = idx.shape[-1]
+    dev = idx.device
+    counts = torch.empty(E, dtype=torch.int32, device=dev)
+    offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    slot_of = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(1, lib.csmoe_bin_workspace_bytes(n, E)), dtype=torch.uint8, device=dev)
+    L.check(lib.csmoe_bin_tokens(idx.data_ptr(), n, E, counts.data_ptr(), offsets.data_ptr(), perm.data_ptr(),
+                                 slot_of.data_ptr(), ws.data_ptr(), _stream()), "bin_tokens")
+    return Bins(counts, offsets, perm, slot_of, n, E, K)
+
+
+# ------------------------------------------------------------------------------------------------ dispatch / combine
+def dispatch_rows(x2: torch.Tensor, bins: Bins) -> torch.Tensor:
+    T, D = x2.shape
+    xs = torch.empty(bins.n, D, dtype=x2.dtype, device=x2.device)
+    L.check(lib.csmoe_dispatch_rows(x2.data_ptr(), bins.perm.data_ptr(), bins.K, xs.data_ptr(), bins.n, D, _dt(x2), _stream()),
+            "dispatch_rows")
+    return xs
+
+
+def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    D = dxs.shape[1]
+    dx = torch.empty(T, D, dtype=dxs.dtype, device=dxs.device)
+    L.check(lib.csmoe_dispatch_rows_bwd(dxs.data_ptr(), bins.slot_of.data_ptr(), bins.K, _ptr(add), dx.data_ptr(), T, D,
+                                        _dt(dxs), _stream()), "dispatch_rows_bwd")
+    return dx
+
+
+def combine(y: torch.Tensor, bins: Bins, idx: torch.Tensor, w: torch.Tensor, mode: int, T: int,
+            obias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    D = y.shape[1]
+    out = torch.empty(T, D, dtype=y.dtype, device=y.device)
+    L.check(lib.csmoe_combine(y.data_ptr(), bins.slot_of.data_ptr(), _ptr(idx), w.data_ptr(), _ptr(obias), out.data_ptr(),
+                              T, bins.K, D, _dt(y), mode, _stream()), "combine")
+    return out
+
+
+def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: torch.Tensor, want_dw: bool = True):
+    T, D = dout.shape
+    dy = torch.empty(bins.n, D, dtype=dout.dtype, device=dout.device)
+    dw = torch.empty(T, bins.K, dtype=torch.float32, device=dout.device) if (want_dw and y is not None) else None
+    L.check(lib.csmoe_combine_bwd(dout.data_ptr(), _ptr(y), bins.perm.data_ptr(), bins.slot_of.data_ptr(), w.data_ptr(),
+                                  dy.data_ptr(), _ptr(dw), T, bins.K, D, _dt(dout), _stream()), "combine_bwd")
+    return dy, dw
+
+
+# ------------------------------------------------------------------------------------------------ grouped GEMMs
+def grouped_gemm(A: torch.Tensor, b_ptrs: torch.Tensor, b_layout: int, ldb: int, N: int, offsets: torch.Tensor, E: int,
+                 bias_ptrs: Optional[torch.Tensor] = None, epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE,
+                 aux: Optional[torch.Tensor] = None, want_c2: bool = False, force_generic: bool = False):
+    M, Kd = A.shape
+    Cm = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    C2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c2 else None
+    L.check(lib.csmoe_grouped_gemm(A.data_ptr(), A.stride(0), b_ptrs.data_ptr(), b_layout, ldb, _ptr(bias_ptrs),
+                                   offsets.data_ptr(), E, M, N, Kd, Cm.data_ptr(), _ptr(C2), _ptr(aux), N, epilogue, act,
+                                   _dt(A), int(force_generic), _stream()), "grouped_gemm")
+    return (Cm, C2) if want_c2 else Cm
+
+
+def dense_gemm(A: torch.Tensor, B: torch.Tensor, b_layout: int, bias: Optional[torch.Tensor] = None,
+               epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE, aux: Optional[torch.Tensor] = None, want_c2: bool = False,
+               force_generic: bool = False):
+    M, Kd = A.shape
+    N = B.shape[0] if b_layout == L.B_NK else B.shape[1]
+    Cm = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    C2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c2 else None
+    L.check(lib.csmoe_dense_gemm(A.data_ptr(), A.stride(0), B.data_ptr(), b_layout, B.stride(0), _ptr(bias), M, N, Kd,
+                                 Cm.data_ptr(), _ptr(C2), _ptr(aux), N, epilogue, act, _dt(A), int(force_generic), _stream()),
+            "dense_gemm")
+    return (Cm, C2) if want_c2 else Cm
+
+
+def grouped_wgrad(A: torch.Tensor, B: torch.Tensor, offsets: torch.Tensor, E: int, out: torch.Tensor,
+                  out_ptrs: torch.Tensor, accumulate: bool = False, force_generic: bool = False):
+    """out[e] = A_e^T @ B_e for every expert; `out` is [E, Na, Nb] (or any buffer the pointers index)."""
+    M, Na = A.shape
+    Nb = B.shape[1]
+    L.check(lib.csmoe_grouped_wgrad(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), offsets.data_ptr(), E, M, Na, Nb,
+                                    out_ptrs.data_ptr(), Nb, _dt(A), _dt(out), int(accumulate), int(force_generic), _stream()),
+            "grouped_wgrad")
+    return out
+
+
+def dense_wgrad(A: torch.Tensor, B: torch.Tensor, out_dtype=None, force_generic: bool = False) -> torch.Tensor:
+    M, Na = A.shape
+    Nb = B.shape[1]
+    out = torch.empty(Na, Nb, dtype=out_dtype or A.dtype, device=A.device)
+    L.check(lib.csmoe_dense_wgrad(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), M, Na, Nb, out.data_ptr(), Nb, _dt(A),
+                                  _dt(out), 0, int(force_generic), _stream()), "dense_wgrad")
+    return out
+
+
+def grouped_colsum(G: torch.Tensor, offsets: torch.Tensor, E: int, out: torch.Tensor, out_ptrs: torch.Tensor):
+    M, N = G.shape
+    L.check(lib.csmoe_grouped_colsum(G.data_ptr(), G.stride(0), offsets.data_ptr(), E, N, out_ptrs.data_ptr(), _dt(G), _dt(out),
+                                     _stream()), "grouped_colsum")
+    return out
+
+
+def dense_colsum(G: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    M, N = G.shape
+    out = torch.empty(N, dtype=out_dtype or G.dtype, device=G.device)
+    L.check(lib.csmoe_dense_colsum(G.data_ptr(), G.stride(0), M, N, out.data_ptr(), _dt(G), _dt(out), _stream()), "dense_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ affinity
+def softplus_mean(y: torch.Tensor) -> torch.Tensor:
+    R, D = y.shape
+    aff = torch.empty(R, dtype=y.dtype, device=y.device)
+    L.check(lib.csmoe_softplus_mean(y.data_ptr(), aff.data_ptr(), R, D, _dt(y), _stream()), "softplus_mean")
+    return aff
+
+
+def softplus_mean_bwd(y: torch.Tensor, daff: torch.Tensor, dy_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    R, D = y.shape
+    dy = torch.empty_like(y)
+    L.check(lib.csmoe_softplus_mean_bwd(y.data_ptr(), daff.data_ptr(), _ptr(dy_add), dy.data_ptr(), R, D, _dt(y), _stream()),
+            "softplus_mean_bwd")
+    return dy

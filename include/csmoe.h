@@ -1,0 +1,165 @@
+/* csmoe.h -- C ABI of the MI355X-native (gfx950) sparse-MoE hot path for CompeteSMoE.
+ *
+ * Drop-in boundary: the reference hides this path behind Python nn.Module classes
+ * (`moe_model/model/moe/` and `moe_pretrain_model/layers/moe/`) whose only native code is the two
+ * Triton kernels of `moe_pretrain_model/layers/cvmm.py`.  Every entry point below replaces a piece of
+ * that path and cites it.  The host side (`competesmoe_amd/`) keeps the reference's module / registry
+ * surface and calls these functions through ctypes with raw device pointers -- no torch types cross
+ * this boundary.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless marked host; tensors are dense row-major;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); nothing synchronises;
+ *   - `dtype` is CSMOE_F32 or CSMOE_BF16 (the activation / weight storage type; accumulation is fp32);
+ *   - T tokens, D model dim, F expert hidden dim, E experts, K selected per token, n = T*K binned rows;
+ *   - "binned row space": rows sorted by expert (stable counting sort), expert e owns rows
+ *     [offsets[e], offsets[e+1]);
+ *   - return value: 0 on success, CSMOE_ERR_* otherwise; csmoe_last_error() gives the message.
+ */
+#ifndef CSMOE_H
+#define CSMOE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* csmoe_stream_t;
+
+enum { CSMOE_F32 = 0, CSMOE_BF16 = 1 };
+enum { CSMOE_ACT_NONE = 0, CSMOE_ACT_RELU = 1, CSMOE_ACT_GELU = 2, CSMOE_ACT_GELU_TANH = 3, CSMOE_ACT_SILU = 4 };
+enum { CSMOE_OK = 0, CSMOE_ERR_INVALID = 1, CSMOE_ERR_LAUNCH = 2, CSMOE_ERR_UNSUPPORTED = 3 };
+
+/* Router selection rule (what top-k runs on, how the K weights are normalised). */
+enum {
+  CSMOE_SEL_SOFTMAX = 0,  /* softmax(fp32) -> topk -> w/sum          moe_model/model/moe/moe.py:129-130, smoe.py:44      */
+  CSMOE_SEL_RAW = 1,      /* topk on raw scores -> w/sum (competition) moe_model/model/moe/competesmoe.py:253-255          */
+  CSMOE_SEL_TOPK_SOFTMAX = 2, /* topk(logits) -> softmax over the K  moe_pretrain_model/layers/moe/deepseekv2.py:140-142 */
+  CSMOE_SEL_SIGMOID = 3   /* topk(sigmoid) -> w/(sum+1e-20)           moe_pretrain_model/layers/moe/deepseekv3.py:147-151 */
+};
+
+/* Combine rounding rule. */
+enum {
+  CSMOE_COMBINE_SEQ = 0,  /* LLaVA compute_moe: experts visited in index order, accumulator rounded to the
+                             activation dtype after every add (moe_model/model/moe/moe.py:204)                        */
+  CSMOE_COMBINE_DOT = 1,  /* cvmm reduction_weight: one fp32 dot over K, rounded once
+                             (moe_pretrain_model/layers/cvmm.py:481-483)                                              */
+  CSMOE_COMBINE_SEQ_RW = 2 /* as SEQ, but the product w*y is rounded to the activation dtype before the add: the
+                             competition branch hands compute_moe weights already in x.dtype
+                             (moe_model/model/moe/competesmoe.py:253-255 -> moe.py:204)                               */
+};
+
+/* GEMM operand layouts for the grouped expert GEMMs. */
+enum {
+  CSMOE_B_NK = 0,  /* per-expert B stored [N, Kd] (nn.Linear weight: y = a @ B^T)  */
+  CSMOE_B_KN = 1   /* per-expert B stored [Kd, N] (cvmm keys/values: y = a @ B)    */
+};
+
+/* Epilogues of the row-space grouped GEMM. */
+enum {
+  CSMOE_EPI_PLAIN = 0,     /* C = round(acc)                                                         */
+  CSMOE_EPI_BIAS = 1,      /* C = round(acc + bias_e[n])                                            */
+  CSMOE_EPI_BIAS_ACT = 2,  /* C = round(acc + bias_e[n]);  C2 = round(act(C))   (bias may be null)  */
+  CSMOE_EPI_ACTGRAD = 3    /* C = round(round(acc) * act'(aux[m,n]))             (GELU/ReLU backward) */
+};
+
+int csmoe_version(void);
+const char* csmoe_last_error(void);
+/* Number of compute units / name of the device `stream` belongs to (host ints). */
+int csmoe_device_info(int* n_cu, int* lds_bytes, char* name, int name_len);
+
+/* ---- router ------------------------------------------------------------------------------------------
+ * gate projection  logits[T,E] = x[T,D] @ w_gate[E,D]^T, rounded to `dtype`
+ * replaces `self.gate(x)` (moe_model/model/moe/smoe.py:42, competesmoe.py:314) and
+ * `F.linear(x, self.w_gate)` (moe_pretrain_model/layers/moe/moe.py:121). */
+int csmoe_gate_logits(const void* x, const void* w_gate, void* logits, int T, int D, int E, int dtype,
+                      csmoe_stream_t stream);
+
+/* scores[T,E] (dtype) -> softmax[T,E] fp32 (of the scores), idx[T,K] int32 (descending value, ties ->
+ * lowest index), w[T,K] fp32.  `round_sum_bf16` != 0 rounds the K-sum to bf16 before the division
+ * (`.to(x.dtype)` on the denominator, smoe.py:44).  softmax may be null for SEL_TOPK_SOFTMAX/SIGMOID.
+ * replaces topk_expert + renorm (moe_model/model/moe/moe.py:113-132; smoe.py:19-44;
+ * competesmoe.py:246-255; pretrain smoe.py:123-143, deepseekv2.py:140-142, deepseekv3.py:147-151). */
+int csmoe_router_select(const void* scores, int dtype, int T, int E, int K, int sel_mode, int round_sum_bf16,
+                        float* softmax, int32_t* idx, float* w, csmoe_stream_t stream);
+
+/* backward of csmoe_router_select: given dw[T,K] (fp32) and optional dsoftmax[T,E] (fp32, from the aux
+ * losses), produce dscores[T,E] in `dtype`.  (autograd of the same reference lines.) */
+int csmoe_router_select_bwd(const void* scores, int dtype, int T, int E, int K, int sel_mode, int round_sum_bf16,
+                            const float* softmax, const int32_t* idx, const float* w, const float* dw,
+                            const float* dsoftmax, void* dscores, csmoe_stream_t stream);
+
+/* ---- binning -----------------------------------------------------------------------------------------
+ * Stable counting sort of idx[n] (expert id per (token,k) slot, n = T*K) into the binned row space.
+ *   counts[E], offsets[E+1]; perm[n]: flat (t*K+k) held by binned row m; slot_of[n]: binned row of flat j.
+ * `workspace` must hold csmoe_bin_workspace_bytes(n, E) bytes.
+ * replaces cvmm_prepare_sel2's sort (moe_pretrain_model/layers/cvmm.py:580-593) and the E `torch.where`
+ * scans of compute_moe (moe_model/model/moe/moe.py:189-191). */
+int64_t csmoe_bin_workspace_bytes(int n, int E);
+int csmoe_bin_tokens(const int32_t* idx, int n, int E, int32_t* counts, int32_t* offsets, int32_t* perm,
+                     int32_t* slot_of, void* workspace, csmoe_stream_t stream);
+
+/* ---- dispatch / combine ------------------------------------------------------------------------------
+ * dispatch: xs[m,:] = x[perm[m] / K, :]                      (gather of x rows, moe.py:201 `x[batch_idx, token_idx]`;
+ *                                                             cvmm.py:114-119 remap_offs_am) */
+int csmoe_dispatch_rows(const void* x, const int32_t* perm, int K, void* xs, int n, int D, int dtype,
+                        csmoe_stream_t stream);
+/* dispatch backward: dx[t,:] = sum_k dxs[slot_of[t*K+k], :] (+ add[t,:] if add != null)   (cvmm.py:544-545) */
+int csmoe_dispatch_rows_bwd(const void* dxs, const int32_t* slot_of, int K, const void* add, void* dx, int T, int D,
+                            int dtype, csmoe_stream_t stream);
+/* combine: out[t,:] = sum_k w[t,k] * y[slot_of[t*K+k], :]  (+ obias[:] if non-null) with the rounding rule `mode`
+ * (moe.py:204; cvmm.py:481-483).  idx gives the expert of each slot (visit order for COMBINE_SEQ).
+ * `scale` multiplies the result (1.0 normally; 0.5 for smoe_share, shard_smoe.py:55 is applied by the caller). */
+int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias,
+                  void* out, int T, int K, int D, int dtype, int mode, csmoe_stream_t stream);
+/* combine backward: dy[m,:] = round(w * dout[t,:]) in the binned row space; dw[t,k] = <dout[t,:], y[slot,:]>
+ * (y may be null -> dw not written).  (autograd of moe.py:204; cvmm.py:497-499,543) */
+int csmoe_combine_bwd(const void* dout, const void* y, const int32_t* perm, const int32_t* slot_of, const float* w,
+                      void* dy, float* dw, int T, int K, int D, int dtype, csmoe_stream_t stream);
+
+/* ---- grouped expert GEMM -----------------------------------------------------------------------------
+ * Row-space GEMM: for every expert e and binned row m in [offsets[e], offsets[e+1]):
+ *     C[m, 0:N] = epilogue( A[m, 0:Kd] (x) B_e )
+ * B_e = b_ptrs[e] is [N,Kd] (CSMOE_B_NK) or [Kd,N] (CSMOE_B_KN) with leading dimension ldb.
+ * bias_ptrs[e] -> [N] or null; C2 / aux are [M,N] with ldc.  M = offsets[E] rows in total (upper bound `M`).
+ * replaces cvmm_kernel (moe_pretrain_model/layers/cvmm.py:61-168, 354-398), the per-expert nn.Linear calls of
+ * compute_moe (moe_model/model/moe/moe.py:196-204) and their grad-input (cvmm.py:519-536). */
+int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                       const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd,
+                       void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, int dtype,
+                       int force_generic, csmoe_stream_t stream);
+
+/* Dense (single weight matrix) form of the same kernel: C[M,N] = epilogue(A[M,Kd] (x) B), used for the gate projection and
+ * the always-on shared expert (moe_model/model/moe/shard_smoe.py:53, deepseekv3.py:44; pretrain deepseekv2.py:154-165). */
+int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, int64_t ldb, const void* bias, int M, int N,
+                     int Kd, void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, int dtype,
+                     int force_generic, csmoe_stream_t stream);
+
+/* Weight-gradient GEMM: for every expert e:  C_e[0:Na, 0:Nb] = sum_{m in expert e} A[m,0:Na]^T B[m,0:Nb]
+ * c_ptrs[e] -> [Na, Nb] (leading dim ldc) written in `out_dtype` (CSMOE_F32 or CSMOE_BF16); empty experts get zeros.
+ * Deterministic (no atomics).  `accumulate` != 0 adds into the existing C_e.
+ * replaces cvmm_backward_kernel3 (cvmm.py:194-345, 421-457) and autograd's per-expert weight grads. */
+int csmoe_grouped_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int M,
+                        int Na, int Nb, void* const* c_ptrs, int64_t ldc, int dtype, int out_dtype, int accumulate,
+                        int force_generic, csmoe_stream_t stream);
+
+/* Dense form: C[Na,Nb] = A[M,Na]^T B[M,Nb]. */
+int csmoe_dense_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int Na, int Nb, void* C, int64_t ldc,
+                      int dtype, int out_dtype, int accumulate, int force_generic, csmoe_stream_t stream);
+
+/* Per-expert column sums (bias gradients): out_e[0:N] = sum_{m in e} G[m, 0:N]; out in `out_dtype`. */
+int csmoe_grouped_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int N, void* const* out_ptrs,
+                         int dtype, int out_dtype, csmoe_stream_t stream);
+
+int csmoe_dense_colsum(const void* G, int64_t ldg, int M, int N, void* out, int dtype, int out_dtype, csmoe_stream_t stream);
+
+/* ---- competition affinity ----------------------------------------------------------------------------
+ * aff[r] = mean_d softplus(y[r, d]) rounded to dtype  (competesmoe.py:242; pretrain competesmoe.py:401) and its
+ * backward dy[r,d] = round(daff[r] / D * sigmoid(y[r,d])) (+ dy_add if non-null). */
+int csmoe_softplus_mean(const void* y, void* aff, int R, int D, int dtype, csmoe_stream_t stream);
+int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype,
+                            csmoe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSMOE_H */

@@ -1,0 +1,367 @@
+"""GPU parity tests of every C-ABI kernel (through ctypes) against plain torch / the CPU oracle.
+
+bit-exact for integer / index work and for exact-integer GEMM data; fp32 <= 1e-5; bf16 compared with a
+fp32 computation of the same bf16 inputs (<= 1 bf16 ulp of rounding, i.e. rel 2^-8)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from competesmoe_amd import ops, _lib as L
+    from oracle import moe_oracle as O
+
+DEV = "cuda"
+
+
+def rand_idx(T, K, E, seed=0, skew=False, empty=()):
+    g = torch.Generator().manual_seed(seed)
+    sc = torch.rand(T, E, generator=g)
+    if skew:
+        sc[:, : max(1, E // 8)] += 0.5
+    for e in empty:
+        sc[:, e] = -1
+    return sc.topk(K, dim=-1).indices.int()
+
+
+# ------------------------------------------------------------------------------------------------ binning
+@pytest.mark.parametrize("T,K,E", [(1, 1, 1), (7, 2, 8), (128, 2, 8), (1000, 3, 64), (4096, 2, 64), (3000, 8, 100),
+                                   (5000, 2, 300), (32768, 2, 64)])
+def test_bin_tokens(T, K, E):
+    idx = rand_idx(T, K, E, seed=T + K, skew=True, empty=(E - 1,) if E > 2 else ())
+    counts, offsets, perm = O.bin_tokens(idx, E)
+    b = ops.bin_tokens(idx.to(DEV), E)
+    assert torch.equal(b.counts.cpu().long(), counts)
+    assert torch.equal(b.offsets.cpu().long(), offsets)
+    assert torch.equal(b.perm.cpu().long(), perm)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel())
+    assert torch.equal(b.slot_of.cpu().long(), inv)
+
+
+def test_bin_tokens_empty_input():
+    b = ops.bin_tokens(torch.zeros(0, 2, dtype=torch.int32, device=DEV), 8)
+    assert int(b.offsets[-1]) == 0 and int(b.counts.sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ dispatch
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,K,E,D", [(5, 2, 4, 8), (300, 2, 8, 64), (1024, 3, 16, 200), (513, 2, 8, 1027), (2048, 2, 64, 4096)])
+def test_dispatch_and_bwd(T, K, E, D, dtype):
+    idx = rand_idx(T, K, E, seed=D).to(DEV)
+    b = ops.bin_tokens(idx, E)
+    x = torch.randn(T, D, device=DEV).to(dtype)
+    xs = ops.dispatch_rows(x, b)
+    assert torch.equal(xs, x[(b.perm // K).long()])
+    # backward: gather-sum of K rows per token (fp32 sum, one rounding)
+    dxs = torch.randn(T * K, D, device=DEV).to(dtype)
+    add = torch.randn(T, D, device=DEV).to(dtype)
+    dx = ops.dispatch_rows_bwd(dxs, b, T)
+    ref = dxs[b.slot_of.long()].view(T, K, D).float().sum(1)
+    tol = 1e-6 if dtype == torch.float32 else 2 ** -8
+    assert torch.allclose(dx.float(), ref.to(dtype).float(), rtol=tol, atol=1e-6)
+    dx2 = ops.dispatch_rows_bwd(dxs, b, T, add=add)
+    ref2 = (ref.to(dtype).float() + add.float()).to(dtype)
+    assert torch.allclose(dx2.float(), ref2.float(), rtol=tol, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ router
+def ref_select(scores, K, mode, round_bf16):
+    s = scores.float()
+    sm = torch.softmax(s, -1)
+    dt = scores.dtype
+    if mode == 0:
+        key = sm
+    elif mode == 3:
+        key = torch.sigmoid(s).to(dt).float()
+    else:
+        key = s
+    idx = O.topk_lowest_index(key.detach(), K)[1]
+    v = torch.gather(key, -1, idx)
+    if mode == 0:
+        den = v.sum(-1, keepdim=True)
+        if round_bf16:
+            den = den.bfloat16().float()
+        w = v / den
+    elif mode == 1:
+        den = v.sum(-1, keepdim=True).to(dt).float()
+        w = (v / den).to(dt).float()
+    elif mode == 2:
+        w = torch.softmax(v, -1)
+    else:
+        den = v.sum(-1, keepdim=True).to(dt).float() + 1e-20
+        w = (v / den).to(dt).float()
+    return sm, idx, w
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("T,E,K", [(1, 4, 1), (77, 8, 2), (512, 64, 2), (300, 63, 7), (256, 128, 8), (64, 300, 4)])
+def test_router_select(T, E, K, mode, dtype):
+    g = torch.Generator().manual_seed(E * 7 + K)
+    scores = (torch.randn(T, E, generator=g) * 2).to(dtype)
+    if mode == 1:
+        scores = scores.abs() + 0.1   # affinities are positive (mean softplus)
+    scores = scores.to(DEV)
+    sm, idx, w = ops.router_select(scores, K, mode, round_sum_bf16=(dtype == torch.bfloat16))
+    rsm, ridx, rw = ref_select(scores.cpu(), K, mode, dtype == torch.bfloat16)
+    assert torch.allclose(sm.cpu(), rsm, rtol=2e-6, atol=1e-8)
+    # indices bit-exact unless the GPU softmax differs from the CPU one in the last ulp on a near-tie
+    if mode in (1, 2, 3) or dtype == torch.bfloat16:
+        assert torch.equal(idx.cpu().long(), ridx)
+    else:
+        mism = (idx.cpu().long() != ridx).any(-1)
+        assert mism.float().mean() < 0.01
+        if mism.any():
+            a = torch.gather(rsm, -1, idx.cpu().long())[mism].sort(-1).values
+            bb = torch.gather(rsm, -1, ridx)[mism].sort(-1).values
+            assert torch.allclose(a, bb, rtol=1e-6)
+    ok = (idx.cpu().long() == ridx).all(-1)
+    assert torch.allclose(w.cpu()[ok], rw[ok], rtol=(1e-5 if dtype == torch.float32 or mode in (0, 2) else 2 ** -7), atol=1e-7)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_router_select_bwd_fp32(mode):
+    T, E, K = 200, 16, 3
+    g = torch.Generator().manual_seed(5)
+    scores = torch.randn(T, E, generator=g)
+    if mode == 1:
+        scores = scores.abs() + 0.1
+    dw = torch.randn(T, K, generator=g)
+    dsm = torch.randn(T, E, generator=g)
+    sd = scores.to(DEV)
+    sm, idx, w = ops.router_select(sd, K, mode, False)
+    ds = ops.router_select_bwd(sd, K, mode, False, sm, idx, w, dw.to(DEV), dsm.to(DEV))
+    # autograd reference with the SAME indices
+    s = scores.clone().requires_grad_(True)
+    smr = torch.softmax(s, -1)
+    ii = idx.cpu().long()
+    if mode == 0:
+        v = torch.gather(smr, -1, ii); wr = v / v.sum(-1, keepdim=True)
+    elif mode == 1:
+        v = torch.gather(s, -1, ii); wr = v / v.sum(-1, keepdim=True)
+    elif mode == 2:
+        wr = torch.softmax(torch.gather(s, -1, ii), -1)
+    else:
+        v = torch.gather(torch.sigmoid(s), -1, ii); wr = v / (v.sum(-1, keepdim=True) + 1e-20)
+    ((wr * dw).sum() + (smr * dsm).sum()).backward()
+    assert torch.allclose(ds.cpu(), s.grad, rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ grouped GEMM
+def make_groups(E, M, seed, empty=True):
+    g = torch.Generator().manual_seed(seed)
+    cuts = torch.sort(torch.randint(0, M + 1, (E - 1,), generator=g)).values
+    off = torch.cat([torch.zeros(1, dtype=torch.long), cuts, torch.tensor([M])])
+    if empty and E > 2:
+        off[2] = off[1]          # expert 1 empty
+    return off.int()
+
+
+def ref_rowspace(A, Bs, b_layout, off, bias, epi, act, aux):
+    M = A.shape[0]
+    N = Bs[0].shape[0] if b_layout == 0 else Bs[0].shape[1]
+    dt = A.dtype
+    out = torch.zeros(M, N, dtype=torch.float64, device=A.device)
+    for e in range(len(Bs)):
+        r0, r1 = int(off[e]), int(off[e + 1])
+        if r1 > r0:
+            Bm = Bs[e].double()
+            out[r0:r1] = A[r0:r1].double() @ (Bm.T if b_layout == 0 else Bm)
+            if bias is not None and epi in (1, 2):
+                out[r0:r1] += bias[e].double()
+    actf = {0: lambda h: h, 1: torch.relu, 2: torch.nn.functional.gelu,
+            3: lambda h: torch.nn.functional.gelu(h, approximate="tanh"), 4: torch.nn.functional.silu}[act]
+    if epi == 3:
+        h = aux.double().requires_grad_(True)
+        d = torch.autograd.grad(actf(h).sum(), h)[0]
+        return (out.to(dt).double() * d).to(dt), None
+    c = out.to(dt)
+    c2 = actf(c.double()).to(dt) if epi == 2 else None
+    return c, c2
+
+
+GEMM_SHAPES = [  # E, M, N, Kd
+    (1, 5, 8, 8), (4, 100, 64, 64), (8, 700, 200, 136), (3, 300, 72, 328), (8, 1500, 256, 192), (64, 5000, 384, 256),
+]
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("b_layout", [0, 1])
+@pytest.mark.parametrize("E,M,N,Kd", GEMM_SHAPES)
+def test_grouped_gemm_plain_and_bias_act(E, M, N, Kd, b_layout, dtype, force_generic):
+    g = torch.Generator().manual_seed(M + N)
+    off = make_groups(E, M, seed=M)
+    A = torch.randn(M, Kd, generator=g).to(dtype).to(DEV)
+    shape = (N, Kd) if b_layout == 0 else (Kd, N)
+    Bs = [(torch.randn(*shape, generator=g) / math.sqrt(Kd)).to(dtype).to(DEV) for _ in range(E)]
+    bias = [(torch.randn(N, generator=g) * 0.5).to(dtype).to(DEV) for _ in range(E)]
+    bp, biasp = ops.ptr_array(Bs, DEV), ops.ptr_array(bias, DEV)
+    offd = off.to(DEV)
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=2 ** -7, atol=2e-2)
+    for act in (2, 1, 3):
+        c, c2 = ops.grouped_gemm(A, bp, b_layout, Bs[0].stride(0), N, offd, E, bias_ptrs=biasp, epilogue=L.EPI_BIAS_ACT, act=act,
+                                 want_c2=True, force_generic=force_generic)
+        rc, rc2 = ref_rowspace(A, Bs, b_layout, off, bias, 2, act, None)
+        assert torch.allclose(c.float(), rc.float(), **tol), (c.float() - rc.float()).abs().max()
+        assert torch.allclose(c2.float(), rc2.float(), **tol)
+    c = ops.grouped_gemm(A, bp, b_layout, Bs[0].stride(0), N, offd, E, force_generic=force_generic)
+    rc, _ = ref_rowspace(A, Bs, b_layout, off, None, 0, 0, None)
+    assert torch.allclose(c.float(), rc.float(), **tol)
+    # activation-gradient epilogue
+    aux = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    c = ops.grouped_gemm(A, bp, b_layout, Bs[0].stride(0), N, offd, E, epilogue=L.EPI_ACTGRAD, act=2, aux=aux,
+                         force_generic=force_generic)
+    rc, _ = ref_rowspace(A, Bs, b_layout, off, None, 3, 2, aux)
+    assert torch.allclose(c.float(), rc.float(), **tol)
+
+
+@pytest.mark.parametrize("b_layout", [0, 1])
+@pytest.mark.parametrize("force_generic", [True, False])
+def test_grouped_gemm_exact_integers(b_layout, force_generic):
+    """{-1,0,1} data, K<=128: every product and partial sum is exact in bf16 -> results must be bit-identical.
+    Asymmetric operands catch a transposed fragment map (guide §3)."""
+    E, M, N, Kd = 5, 777, 264, 128
+    g = torch.Generator().manual_seed(3)
+    off = make_groups(E, M, seed=11)
+    A = torch.randint(-1, 2, (M, Kd), generator=g).bfloat16().to(DEV)
+    shape = (N, Kd) if b_layout == 0 else (Kd, N)
+    Bs = [torch.randint(-1, 2, shape, generator=g).bfloat16().to(DEV) for _ in range(E)]
+    c = ops.grouped_gemm(A, ops.ptr_array(Bs, DEV), b_layout, Bs[0].stride(0), N, off.to(DEV), E, force_generic=force_generic)
+    rc, _ = ref_rowspace(A, Bs, b_layout, off, None, 0, 0, None)
+    assert torch.equal(c, rc)
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("dtype,out_dtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                             (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("E,M,Na,Nb", [(1, 3, 8, 8), (4, 100, 64, 72), (8, 900, 200, 136), (8, 2000, 256, 384), (64, 4000, 128, 64)])
+def test_grouped_wgrad(E, M, Na, Nb, dtype, out_dtype, force_generic):
+    g = torch.Generator().manual_seed(M)
+    off = make_groups(E, M, seed=M + 1)
+    A = torch.randn(M, Na, generator=g).to(dtype).to(DEV)
+    B = torch.randn(M, Nb, generator=g).to(dtype).to(DEV)
+    out = torch.full((E, Na, Nb), float("nan"), dtype=out_dtype, device=DEV)
+    ptrs = ops.ptr_array([out[e] for e in range(E)], DEV)
+    ops.grouped_wgrad(A, B, off.to(DEV), E, out, ptrs, force_generic=force_generic)
+    ref = torch.zeros(E, Na, Nb, dtype=torch.float64, device=DEV)
+    for e in range(E):
+        r0, r1 = int(off[e]), int(off[e + 1])
+        ref[e] = A[r0:r1].double().T @ B[r0:r1].double()
+    scale = ref.abs().max().item() + 1e-9
+    err = (out.double() - ref).abs().max().item() / scale
+    assert err <= (1e-5 if out_dtype == torch.float32 and dtype == torch.float32 else (1e-5 if out_dtype == torch.float32 else 2 ** -8)), err
+    # accumulate
+    if out_dtype == torch.float32:
+        ops.grouped_wgrad(A, B, off.to(DEV), E, out, ptrs, accumulate=True, force_generic=force_generic)
+        assert (out.double() - 2 * ref).abs().max().item() / scale <= 2e-5
+
+
+def test_wgrad_exact_integers():
+    E, M, Na, Nb = 3, 100, 136, 264
+    g = torch.Generator().manual_seed(9)
+    off = torch.tensor([0, 100, 100, 100], dtype=torch.int32)   # <= 128 rows per expert keeps sums exact in bf16
+    A = torch.randint(-1, 2, (M, Na), generator=g).bfloat16().to(DEV)
+    B = torch.randint(-1, 2, (M, Nb), generator=g).bfloat16().to(DEV)
+    for fg in (True, False):
+        out = torch.full((E, Na, Nb), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.grouped_wgrad(A, B, off.to(DEV), E, out, ops.ptr_array([out[e] for e in range(E)], DEV), force_generic=fg)
+        ref = torch.zeros(E, Na, Nb, device=DEV)
+        ref[0] = A.float().T @ B.float()
+        assert torch.equal(out.float(), ref), fg
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dense_gemm_and_gate(dtype):
+    T, D, E = 1000, 256, 64
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(T, D, generator=g).to(dtype).to(DEV)
+    wg = (torch.randn(E, D, generator=g) * 0.02).to(dtype).to(DEV)
+    lg = ops.gate_logits(x, wg)
+    ref = (x.double() @ wg.double().T).to(dtype)
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2 ** -7, atol=1e-3)
+    assert torch.allclose(lg.float(), ref.float(), **tol)
+    W = (torch.randn(D, 320, generator=g) / 16).to(dtype).to(DEV)
+    bias = torch.randn(320, generator=g).to(dtype).to(DEV)
+    c, c2 = ops.dense_gemm(x, W, L.B_KN, bias=bias, epilogue=L.EPI_BIAS_ACT, act=L.ACT_RELU, want_c2=True)
+    r = (x.double() @ W.double() + bias.double()).to(dtype)
+    assert torch.allclose(c.float(), r.float(), **tol) and torch.allclose(c2.float(), torch.relu(r).float(), **tol)
+    gw = ops.dense_wgrad(x, c)
+    rg = (x.double().T @ c.double())
+    assert (gw.double() - rg).abs().max() / rg.abs().max() <= (1e-5 if dtype == torch.float32 else 2 ** -8)
+
+
+# ------------------------------------------------------------------------------------------------ combine
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("T,K,E,D", [(3, 1, 2, 8), (200, 2, 8, 64), (1000, 3, 16, 200), (512, 2, 64, 4096), (100, 8, 64, 33)])
+def test_combine_and_bwd(T, K, E, D, mode, dtype):
+    idx = rand_idx(T, K, E, seed=D + K).to(DEV)
+    b = ops.bin_tokens(idx, E)
+    g = torch.Generator().manual_seed(D)
+    y = torch.randn(T * K, D, generator=g).to(dtype).to(DEV)
+    w = torch.rand(T, K, generator=g).to(DEV)
+    if mode == 2:
+        w = w.to(dtype).float()
+    out = ops.combine(y, b, idx, w, mode, T)
+    yk = y[b.slot_of.long()].view(T, K, D)
+    if mode == 1:
+        ref = (w.unsqueeze(-1) * yk.float()).sum(1).to(dtype)
+        tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2 ** -7, atol=1e-6)
+        assert torch.allclose(out.float(), ref.float(), **tol)
+    else:
+        order = idx.long().argsort(dim=-1, stable=True)
+        ref = torch.zeros(T, D, dtype=dtype, device=DEV)
+        for j in range(K):
+            k = order[:, j]
+            yj = yk[torch.arange(T), k].float()
+            wj = w[torch.arange(T), k].unsqueeze(-1)
+            prod = wj * yj
+            if mode == 2:
+                prod = prod.to(dtype).float()
+            ref = (ref.float() + prod).to(dtype)
+        assert torch.equal(out, ref)
+    dout = torch.randn(T, D, generator=g).to(dtype).to(DEV)
+    dy, dw = ops.combine_bwd(dout, y, b, w)
+    flat_t = (b.perm // K).long()
+    wf = w.flatten()[b.perm.long()]
+    rdy = (dout[flat_t].float() * wf.unsqueeze(-1)).to(dtype)
+    assert torch.equal(dy, rdy)
+    rdw = (dout.float().unsqueeze(1) * yk.float()).sum(-1)
+    assert torch.allclose(dw, rdw, rtol=1e-4, atol=1e-4 * D ** 0.5)
+
+
+# ------------------------------------------------------------------------------------------------ small reductions
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum_and_softplus(dtype):
+    E, M, N = 8, 1500, 200
+    off = make_groups(E, M, seed=4)
+    g = torch.Generator().manual_seed(2)
+    G = torch.randn(M, N, generator=g).to(dtype).to(DEV)
+    out = torch.full((E, N), float("nan"), dtype=dtype, device=DEV)
+    ops.grouped_colsum(G, off.to(DEV), E, out, ops.ptr_array([out[e] for e in range(E)], DEV))
+    ref = torch.stack([G[int(off[e]):int(off[e + 1])].double().sum(0) for e in range(E)])
+    assert (out.double() - ref).abs().max() <= (1e-4 if dtype == torch.float32 else 0.5)
+    d = ops.dense_colsum(G)
+    assert (d.double() - G.double().sum(0)).abs().max() <= (1e-3 if dtype == torch.float32 else 1.0)
+    y = (torch.randn(300, 96, generator=g) * 3).to(dtype).to(DEV)
+    aff = ops.softplus_mean(y)
+    raff = torch.nn.functional.softplus(y.float()).to(dtype).float().mean(-1).to(dtype)
+    assert torch.allclose(aff.float(), raff.float(), rtol=(1e-5 if dtype == torch.float32 else 2 ** -7), atol=1e-6)
+    daff = torch.randn(300, generator=g).to(dtype).to(DEV)
+    dy = ops.softplus_mean_bwd(y, daff)
+    rdy = ((daff.float() / 96).to(dtype).float().unsqueeze(-1) * torch.sigmoid(y.float())).to(dtype)
+    assert torch.allclose(dy.float(), rdy.float(), rtol=(1e-5 if dtype == torch.float32 else 2 ** -7), atol=1e-7)
+
+
+def test_argument_errors_raise():
+    x = torch.randn(4, 8, device=DEV)
+    with pytest.raises(ValueError):
+        ops.router_select(x, 9, 0, False)          # K > E
+    with pytest.raises(ValueError):
+        ops.router_select(x.half(), 2, 0, False)   # unsupported dtype
+    with pytest.raises(ValueError):
+        ops.bin_tokens(torch.zeros(4, 2, dtype=torch.int64, device=DEV), 4)
