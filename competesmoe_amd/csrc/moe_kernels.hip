@@ -287,6 +287,7 @@ constexpr int MAXK = 64;   // one lane per selected slot
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t* slot_of, const int32_t* idx, const float* w,
                                                       const T* obias, const T* add, T* out, int Tn, int K, int D, int mode) {
+#pragma clang fp contract(off)   // the sequential rule is "multiply, round, add, round": no FMA contraction
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
@@ -308,7 +309,10 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
     } else {
       rank = lane;
     }
-    for (int d0 = lane * VEC; d0 < D; d0 += 64 * VEC) {
+    // the d-loop is wave-uniform (ballot / shuffle inside need every lane); `live` guards the memory accesses
+    for (int dbase = 0; dbase < D; dbase += 64 * VEC) {
+      const int d0 = dbase + lane * VEC;
+      const bool live = d0 < D;
       float acc[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
@@ -316,30 +320,37 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
         const int src = __ffsll((unsigned long long)__ballot(lane < K && rank == kk)) - 1;
         const int sl = __shfl(myslot, src, 64);
         const float wv = __shfl(myw, src, 64);
-        const T* row = y + (int64_t)sl * D + d0;
         float yv[VEC];
-        if constexpr (VEC == 8) {
-          bf16x8 r8 = *(const bf16x8*)row;
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) yv[v] = (float)r8[v];
-        } else if constexpr (VEC == 4) {
-          f32x4 r4 = *(const f32x4*)row;
+        for (int v = 0; v < VEC; ++v) yv[v] = 0.f;
+        if (live) {
+          const T* row = y + (int64_t)sl * D + d0;
+          if constexpr (VEC == 8) {
+            bf16x8 r8 = *(const bf16x8*)row;
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) yv[v] = r4[v];
-        } else {
-          yv[0] = DT<T>::ld(row);
+            for (int v = 0; v < VEC; ++v) yv[v] = (float)r8[v];
+          } else if constexpr (VEC == 4) {
+            f32x4 r4 = *(const f32x4*)row;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) yv[v] = r4[v];
+          } else {
+            yv[0] = DT<T>::ld(row);
+          }
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           if (mode == CSMOE_COMBINE_DOT) {
             acc[v] = fmaf(wv, yv[v], acc[v]);
           } else {
-            float prod = __fmul_rn(wv, yv[v]);
+            // written out (not __fmul_rn/__fadd_rn: those inline as contractable a*b / a+b) under contract(off)
+            float prod = wv * yv[v];
             if (mode == CSMOE_COMBINE_SEQ_RW) prod = DT<T>::rnd(prod);
-            acc[v] = DT<T>::rnd(__fadd_rn(acc[v], prod));
+            float sum = acc[v] + prod;
+            acc[v] = DT<T>::rnd(sum);
           }
         }
       }
+      if (!live) continue;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         float r = acc[v];

@@ -1,0 +1,286 @@
+"""torch.autograd.Function wrappers: every forward/backward below is a sequence of C-ABI HIP kernel launches
+(competesmoe_amd.ops).  No torch math on the hot path; torch only owns memory, streams and the autograd graph.
+
+Reference parity notes are on each class (file:line of the reference code whose forward AND autograd it replaces).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def _flip(layout: int) -> int:
+    return L.B_KN if layout == L.B_NK else L.B_NK
+
+
+# ======================================================================================================== gate
+class GateLogits(torch.autograd.Function):
+    """logits = x @ w_gate^T rounded to x.dtype -- `self.gate(x)` (moe_model/model/moe/smoe.py:42) /
+    `F.linear(x, self.w_gate)` (moe_pretrain_model/layers/moe/moe.py:121)."""
+
+    @staticmethod
+    def forward(ctx, x2: torch.Tensor, w_gate: torch.Tensor):
+        x2 = x2.contiguous()
+        wg = w_gate.contiguous()
+        if wg.dtype != x2.dtype:
+            wg = wg.to(x2.dtype)
+        ctx.save_for_backward(x2, wg)
+        ctx.w_dtype = w_gate.dtype
+        return ops.gate_logits(x2, wg)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x2, wg = ctx.saved_tensors
+        dlogits = dlogits.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.dense_gemm(dlogits, wg, L.B_KN)                   # [T,E] @ [E,D]
+        if ctx.needs_input_grad[1]:
+            dw = ops.dense_wgrad(dlogits, x2, out_dtype=ctx.w_dtype)   # [E,D] = dlogits^T x
+        return dx, dw
+
+
+# ======================================================================================================== router
+class RouterSelect(torch.autograd.Function):
+    """softmax / top-k / renormalise in one wave-per-token kernel.  Returns (softmax fp32 [T,E], idx int32 [T,K],
+    w fp32 [T,K]).  moe_model/model/moe/moe.py:113-132, smoe.py:44, competesmoe.py:246-255 and the pretrain
+    variants (deepseekv2.py:140-142, deepseekv3.py:147-151)."""
+
+    @staticmethod
+    def forward(ctx, scores: torch.Tensor, K: int, mode: int, round_sum_bf16: bool):
+        scores = scores.contiguous()
+        sm, idx, w = ops.router_select(scores, K, mode, round_sum_bf16, want_softmax=True)
+        ctx.save_for_backward(scores, sm, idx, w)
+        ctx.cfg = (K, mode, round_sum_bf16)
+        ctx.mark_non_differentiable(idx)
+        return sm, idx, w
+
+    @staticmethod
+    def backward(ctx, dsm, _didx, dw):
+        scores, sm, idx, w = ctx.saved_tensors
+        K, mode, rb = ctx.cfg
+        dsm = None if dsm is None else dsm.contiguous().float()
+        dw = None if dw is None else dw.contiguous().float()
+        ds = ops.router_select_bwd(scores, K, mode, rb, sm, idx, w, dw, dsm)
+        return ds, None, None, None
+
+
+# ======================================================================================================== expert FFN
+@dataclass
+class ExpertTable:
+    """Device pointer tables + static description of E two-matrix experts."""
+    E: int
+    D: int            # input dim
+    F: int            # hidden dim
+    Dout: int         # output dim
+    layout: int       # B_NK: w1 [F,D], w2 [Dout,F] (nn.Linear);  B_KN: w1 [D,F], w2 [F,Dout] (cvmm keys/values)
+    act: int
+    w1_ptrs: torch.Tensor
+    w2_ptrs: torch.Tensor
+    b1_ptrs: Optional[torch.Tensor] = None
+    b2_ptrs: Optional[torch.Tensor] = None
+    param_dtype: torch.dtype = torch.float32   # dtype of the gradients handed back
+
+
+def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias):
+    T = x2.shape[0]
+    bins = ops.bin_tokens(idx, tab.E)
+    xs = ops.dispatch_rows(x2, bins)
+    ld1 = tab.D if tab.layout == L.B_NK else tab.F
+    ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
+    hpre, hact = ops.grouped_gemm(xs, tab.w1_ptrs, tab.layout, ld1, tab.F, bins.offsets, tab.E, bias_ptrs=tab.b1_ptrs,
+                                  epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True)
+    y = ops.grouped_gemm(hact, tab.w2_ptrs, tab.layout, ld2, tab.Dout, bins.offsets, tab.E, bias_ptrs=tab.b2_ptrs,
+                         epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
+    out = ops.combine(y, bins, idx, w, combine_mode, T, obias=obias)
+    return out, (bins, xs, hpre, hact, y)
+
+
+def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool):
+    """Returns dx2, dw, (gW1 [E,..], gb1 [E,F]|None, gW2 [E,..], gb2 [E,Dout]|None)."""
+    bins, xs, hpre, hact, y = saved
+    T = dout.shape[0]
+    dev = dout.device
+    E = tab.E
+    dy, dw = ops.combine_bwd(dout.contiguous(), y if need_dw else None, bins, w, want_dw=need_dw)
+    ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
+    ld1 = tab.D if tab.layout == L.B_NK else tab.F
+    # dH = dY @ W2 (+ activation backward in the epilogue)
+    dh = ops.grouped_gemm(dy, tab.w2_ptrs, _flip(tab.layout), ld2, tab.F, bins.offsets, E, epilogue=L.EPI_ACTGRAD,
+                          act=tab.act, aux=hpre)
+    grads = None
+    if need_params:
+        pd = tab.param_dtype
+        es = torch.tensor([], dtype=pd).element_size()
+
+        def table(buf):
+            stride = buf[0].numel() * es
+            return buf.data_ptr() + torch.arange(E, device=dev, dtype=torch.int64) * stride
+
+        if tab.layout == L.B_NK:
+            gW2 = torch.empty(E, tab.Dout, tab.F, dtype=pd, device=dev)
+            ops.grouped_wgrad(dy, hact, bins.offsets, E, gW2, table(gW2))
+            gW1 = torch.empty(E, tab.F, tab.D, dtype=pd, device=dev)
+            ops.grouped_wgrad(dh, xs, bins.offsets, E, gW1, table(gW1))
+        else:
+            gW2 = torch.empty(E, tab.F, tab.Dout, dtype=pd, device=dev)
+            ops.grouped_wgrad(hact, dy, bins.offsets, E, gW2, table(gW2))
+            gW1 = torch.empty(E, tab.D, tab.F, dtype=pd, device=dev)
+            ops.grouped_wgrad(xs, dh, bins.offsets, E, gW1, table(gW1))
+        gb1 = gb2 = None
+        if tab.b2_ptrs is not None:
+            gb2 = torch.empty(E, tab.Dout, dtype=pd, device=dev)
+            ops.grouped_colsum(dy, bins.offsets, E, gb2, table(gb2))
+        if tab.b1_ptrs is not None:
+            gb1 = torch.empty(E, tab.F, dtype=pd, device=dev)
+            ops.grouped_colsum(dh, bins.offsets, E, gb1, table(gb1))
+        grads = (gW1, gb1, gW2, gb2)
+    dx2 = None
+    if need_dx:
+        dxs = ops.grouped_gemm(dh, tab.w1_ptrs, _flip(tab.layout), ld1, tab.D, bins.offsets, E)
+        dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
+    return dx2, dw, grads
+
+
+class MoEFFNModules(torch.autograd.Function):
+    """dispatch -> grouped GEMM(+bias, act) -> grouped GEMM(+bias) -> combine for experts held as SEPARATE nn.Module
+    parameters (LLaVA stack).  Replaces MoeLayer.compute_moe (moe_model/model/moe/moe.py:172-213) and its autograd.
+
+    `params` = w1_0..w1_{E-1}, [b1_0..], w2_0.., [b2_0..]; they are only listed so autograd routes their gradients --
+    the kernels read them through the pointer tables in `tab`."""
+
+    @staticmethod
+    def forward(ctx, x2, w, idx, tab: ExpertTable, combine_mode: int, *params):
+        x2 = x2.contiguous()
+        out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, None)
+        ctx.tab, ctx.saved, ctx.w = tab, saved, w
+        ctx.n_params = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tab = ctx.tab
+        need_params = any(ctx.needs_input_grad[5:])
+        dx2, dw, grads = _ffn_backward(dout, ctx.w, tab, ctx.saved, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                       need_params)
+        ctx.saved = None
+        pg: List[Optional[torch.Tensor]] = [None] * ctx.n_params
+        if grads is not None:
+            gW1, gb1, gW2, gb2 = grads
+            E = tab.E
+            seq = [gW1] + ([gb1] if gb1 is not None else []) + [gW2] + ([gb2] if gb2 is not None else [])
+            pg = [g[e] for g in seq for e in range(E)]
+        return (dx2, dw, None, None, None, *pg)
+
+
+class MoEFFNPacked(torch.autograd.Function):
+    """Same pipeline for PACKED expert weights keys[E,D,F], values[E,F,Dout] (pretrain stack): the two `cvmm` calls of
+    MoE.compute_scores / the reduction-weight cvmm (moe_pretrain_model/layers/moe/moe.py:397-435, smoe.py:240-248) and
+    CVMM.backward (layers/cvmm.py:490-551).  keys/values may be fp32 masters while x is bf16 (autocast): operands are
+    cast once per call, gradients come back in the master dtype."""
+
+    @staticmethod
+    def forward(ctx, x2, w, idx, keys, values, bias, o_bias, act: int, combine_mode: int):
+        x2 = x2.contiguous()
+        op = x2.dtype
+        E, D, F = keys.shape
+        Dout = values.shape[2]
+        dev = x2.device
+        k_op = keys.contiguous() if keys.dtype == op else keys.to(op)
+        v_op = values.contiguous() if values.dtype == op else values.to(op)
+        es = k_op.element_size()
+        ar = torch.arange(E, device=dev, dtype=torch.int64)
+        b_op = None
+        b1 = None
+        if bias is not None:
+            b_op = bias.contiguous() if bias.dtype == op else bias.to(op)
+            b1 = b_op.data_ptr() + ar * (F * es)
+        ob = None
+        if o_bias is not None:
+            ob = o_bias.contiguous() if o_bias.dtype == op else o_bias.to(op)
+        tab = ExpertTable(E=E, D=D, F=F, Dout=Dout, layout=L.B_KN, act=act,
+                          w1_ptrs=k_op.data_ptr() + ar * (D * F * es), w2_ptrs=v_op.data_ptr() + ar * (F * Dout * es),
+                          b1_ptrs=b1, b2_ptrs=None, param_dtype=keys.dtype)
+        out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, ob)
+        ctx.tab, ctx.saved, ctx.w = tab, saved, w
+        ctx.keep = (k_op, v_op, b_op)       # keep the cast copies alive: the pointer tables reference them
+        ctx.has = (bias is not None, o_bias is not None)
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        ctx.ob_dtype = None if o_bias is None else o_bias.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tab = ctx.tab
+        need_params = ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+        dx2, dw, grads = _ffn_backward(dout, ctx.w, tab, ctx.saved, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                       need_params)
+        ctx.saved = None
+        gk = gv = gb = gob = None
+        if grads is not None:
+            gk, gb1, gv, _ = grads
+            if ctx.has[0]:
+                gb = gb1 if gb1.dtype == ctx.bias_dtype else gb1.to(ctx.bias_dtype)
+        if ctx.has[1] and ctx.needs_input_grad[6]:
+            gob = ops.dense_colsum(dout.contiguous(), out_dtype=ctx.ob_dtype)
+        return dx2, dw, None, gk, gv, gb, gob, None, None
+
+
+# ======================================================================================================== dense FFN
+class DenseFFN(torch.autograd.Function):
+    """One always-on expert over all tokens: Linear(+b) -> act -> Linear(+b).  The shared expert of `smoe_share` /
+    `deepseekv3` (moe_model/model/moe/shard_smoe.py:53, deepseekv3.py:44), the pretrain shared cvmm with an all-zero
+    selection (deepseekv2.py:154-165) and each expert of the dense competition pass (competesmoe.py:240-243)."""
+
+    @staticmethod
+    def forward(ctx, x2, w1, b1, w2, b2, act: int, layout: int):
+        x2 = x2.contiguous()
+        op = x2.dtype
+        cast = lambda t: None if t is None else (t.contiguous() if t.dtype == op else t.to(op))
+        w1o, b1o, w2o, b2o = cast(w1), cast(b1), cast(w2), cast(b2)
+        hpre, hact = ops.dense_gemm(x2, w1o, layout, bias=b1o, epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True)
+        y = ops.dense_gemm(hact, w2o, layout, bias=b2o, epilogue=L.EPI_BIAS if b2o is not None else L.EPI_PLAIN)
+        ctx.save_for_backward(x2, w1o, w2o, hpre, hact)
+        ctx.cfg = (act, layout, w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1o, w2o, hpre, hact = ctx.saved_tensors
+        act, layout, dt_w1, dt_b1, dt_w2, dt_b2 = ctx.cfg
+        dy = dy.contiguous()
+        dh = ops.dense_gemm(dy, w2o, _flip(layout), epilogue=L.EPI_ACTGRAD, act=act, aux=hpre)
+        gw1 = gb1 = gw2 = gb2 = dx = None
+        if ctx.needs_input_grad[3]:
+            gw2 = ops.dense_wgrad(dy, hact, out_dtype=dt_w2) if layout == L.B_NK else ops.dense_wgrad(hact, dy, out_dtype=dt_w2)
+        if dt_b2 is not None and ctx.needs_input_grad[4]:
+            gb2 = ops.dense_colsum(dy, out_dtype=dt_b2)
+        if ctx.needs_input_grad[1]:
+            gw1 = ops.dense_wgrad(dh, x2, out_dtype=dt_w1) if layout == L.B_NK else ops.dense_wgrad(x2, dh, out_dtype=dt_w1)
+        if dt_b1 is not None and ctx.needs_input_grad[2]:
+            gb1 = ops.dense_colsum(dh, out_dtype=dt_b1)
+        if ctx.needs_input_grad[0]:
+            dx = ops.dense_gemm(dh, w1o, _flip(layout))
+        return dx, gw1, gb1, gw2, gb2, None, None
+
+
+# ======================================================================================================== affinity
+class SoftplusMean(torch.autograd.Function):
+    """aff[r] = mean_d softplus(y[r,d]) in y.dtype -- `torch.mean(F.softplus(out_i), dim=-1)`
+    (moe_model/model/moe/competesmoe.py:242; pretrain competesmoe.py:401)."""
+
+    @staticmethod
+    def forward(ctx, y2):
+        y2 = y2.contiguous()
+        ctx.save_for_backward(y2)
+        return ops.softplus_mean(y2)
+
+    @staticmethod
+    def backward(ctx, daff):
+        (y2,) = ctx.saved_tensors
+        return ops.softplus_mean_bwd(y2, daff.contiguous().to(y2.dtype))

@@ -1,0 +1,146 @@
+"""`competesmoe`: router policy on ordinary steps, competition policy (every expert runs densely, top-K by mean-softplus
+affinity, router distilled towards it) on scheduled steps -- moe_model/model/moe/competesmoe.py:8-415."""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .. import _lib as L
+from ..functional import RouterSelect, SoftplusMean
+from .register import register_moe
+from .moe import MoeLayer
+
+
+@register_moe("competesmoe")
+class CompeteSMoE(MoeLayer):
+    def __init__(self, in_embed_dim=768, out_embed_dim=768, num_of_experts=4, num_selected=2, expert=None, args=None):
+        super().__init__(in_embed_dim, out_embed_dim, num_of_experts, num_selected, expert, args)
+        if args is None or not hasattr(args, "rate_flip"):
+            raise ValueError("The 'args' parameter must have the attribute 'rate_flip'.")
+        if not hasattr(args, "warm_up"):
+            raise ValueError("The 'args' parameter must include 'warm_up'.")
+        self.warm_up = args.warm_up
+        self.rate_flip = args.rate_flip
+        self.total_steps = None
+        self.current_steps = 0
+        self.step_warm = None
+        self.is_prob_flips = True
+        self.register_buffer("prob_flips", torch.zeros(15801))   # same placeholder shape as competesmoe.py:32
+        self._flips_host = None
+        self.init_gate_weights()
+
+    # ------------------------------------------------------------------ schedule (competesmoe.py:35-179)
+    def set_total_steps(self, total_steps, id_layer, prob_flips_final):
+        assert id_layer is not None, "You must setup id layer is not None"
+        assert prob_flips_final is not None, "You must setup prob_flips_final is not None"
+        self.total_steps = total_steps
+        self.step_warm = int(self.warm_up * self.total_steps)
+        flip_steps = self.total_steps - self.step_warm
+        self.flip_steps = flip_steps
+        if flip_steps <= 0:
+            raise ValueError("self.total_steps - self.step_warm must be greater than 0.")
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        device = self.gate.weight.device
+        cap = self.args.max_compete_in_iter
+        if rank == 0:
+            # host-side restatement of create_balanced_flip_current (:86-130): one torch.rand(1) per slot on the SAME
+            # device RNG stream the reference uses (cuda if available else cpu), left-then-right shifting at the cap
+            rng_dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+            freq = [0] * flip_steps
+            for v in prob_flips_final.values():
+                for i, b in enumerate(v.tolist()):
+                    freq[i] += int(b)
+            cur = [False] * flip_steps
+            for i in range(flip_steps):
+                if torch.rand(1, device=rng_dev).item() < self.rate_flip:
+                    if freq[i] < cap:
+                        cur[i] = True
+                        freq[i] += 1
+                    else:
+                        found = False
+                        for j in range(i - 1, -1, -1):
+                            if freq[j] < cap and not cur[j]:
+                                cur[j], found = True, True
+                                freq[j] += 1
+                                break
+                        if not found:
+                            for j in range(i + 1, flip_steps):
+                                if freq[j] < cap and not cur[j]:
+                                    cur[j] = True
+                                    freq[j] += 1
+                                    break
+            probs_current = torch.tensor(cur, dtype=torch.bool, device=device)
+        else:
+            probs_current = torch.empty(flip_steps, dtype=torch.bool, device=device)
+        if world > 1:
+            dist.broadcast(probs_current, src=0)
+        prob_flips_final[id_layer] = probs_current
+        self.prob_flips = probs_current
+        self._flips_host = probs_current.tolist()     # one host copy: the per-step branch test needs no device sync
+        self.is_prob_flips = False
+        return prob_flips_final
+
+    def set_current_steps(self, step):
+        self.current_steps = step
+
+    def _competing(self, x) -> bool:
+        """competesmoe.py:347 -- x.requires_grad and scheduled; read from the host copy instead of `.item()`."""
+        if not x.requires_grad or self.step_warm is None or self.current_steps < self.step_warm:
+            return False
+        i = self.current_steps - self.step_warm
+        if self._flips_host is None or len(self._flips_host) != self.prob_flips.numel():
+            self._flips_host = self.prob_flips.tolist()       # buffer replaced (e.g. load_state_dict): refresh once
+        return bool(self._flips_host[i] == 1)
+
+    # ------------------------------------------------------------------ policies
+    def router_policy(self, x):
+        gate_logits = self.gate_logits(x)
+        weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
+        return weights, selected_experts, gate_softmax, gate_logits
+
+    def competition_policy(self, x):
+        """competesmoe.py:219-259: every expert densely (DenseFFN kernels), affinity = mean softplus (SoftplusMean kernel),
+        softmax fp32 + top-K on the RAW affinities + renormalisation in x.dtype (RouterSelect, SEL_RAW)."""
+        B, N, D = x.shape
+        outs = [self.dense_expert(i, x) for i in range(self.num_of_experts)]
+        aff = torch.stack([SoftplusMean.apply(o.reshape(B * N, -1)) for o in outs], dim=-1)      # [T,E] x.dtype
+        scores = torch.sigmoid(aff) if getattr(self.args, "norm_sigmoid", False) else aff
+        if getattr(self.args, "norm_sigmoid", False):
+            asm = F.softmax(aff, dim=-1, dtype=torch.float32)
+            _, idx, w = RouterSelect.apply(scores, self.num_selected, L.SEL_RAW, False)
+        else:
+            asm, idx, w = RouterSelect.apply(scores, self.num_selected, L.SEL_RAW, False)
+        expert_outputs = torch.stack(outs, dim=2)                                                   # [B,N,E,Dout]
+        idx_l = idx.view(B, N, -1).long()
+        topk = torch.gather(expert_outputs, 2, idx_l.unsqueeze(-1).expand(B, N, self.num_selected, expert_outputs.size(-1)))
+        return w.view(B, N, -1), idx.view(B, N, -1), asm.view(B, N, -1), aff.view(B, N, -1), topk
+
+    def router_loss(self, gate_softmax, affinity_softmax):
+        return F.mse_loss(gate_softmax, affinity_softmax)
+
+    def forward(self, x, return_id_experts=False, is_vision=False):
+        gate_weights, gate_selected_experts, gate_softmax, gate_logits = self.router_policy(x)
+        auxiliary_loss = torch.tensor(0.0, device=x.device, dtype=x.dtype)
+        infor_aux = {}
+        if self._competing(x):
+            aff_w, aff_idx, aff_softmax, aff_scores, expert_outputs = self.competition_policy(x)
+            routerloss = self.router_loss(gate_softmax=gate_softmax, affinity_softmax=aff_softmax.detach())
+            if getattr(self.args, "hybrid", False):
+                il = aff_idx.long()
+                routerloss = routerloss + self.router_loss(
+                    affinity_softmax=torch.gather(aff_softmax, -1, il).detach(),
+                    gate_softmax=torch.gather(gate_softmax, -1, il)) * self.args.router_theta
+            diversity_loss = self.experts_diversity_loss(expert_outputs=expert_outputs)
+            balance_loss = self.balanceloss(selected_experts=aff_idx, gate_softmax=aff_softmax)
+            auxiliary_loss = (routerloss * self.args.router_loss_coef + diversity_loss * self.args.diversity_loss_coef
+                              + balance_loss * self.args.bal_comp_loss_coef)
+            # the reference re-runs the K selected experts from x (competesmoe.py:374-379); weights are already x.dtype
+            output = self.compute_moe(aff_idx, aff_w, None, x, weights_rounded=True)
+            infor_aux = {"balance_loss": balance_loss.clone().detach(), "diversity_loss": diversity_loss.clone().detach(),
+                         "routerloss": routerloss.clone().detach()}
+        else:
+            output = self.compute_moe(gate_selected_experts, gate_weights, None, x)
+            if x.requires_grad or return_id_experts:
+                auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(
+                    selected_experts=gate_selected_experts, gate_softmax=gate_softmax, gate_logits=gate_logits)
+                infor_aux = {"balance_loss": balance_loss.clone().detach(), "router_z_loss": router_z_loss.clone().detach()}
+        return output, auxiliary_loss, None, infor_aux

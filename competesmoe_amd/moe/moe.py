@@ -1,0 +1,213 @@
+"""MoeLayer: base class of the LLaVA-stack MoE layers, HIP-backed.
+
+Same constructor, attributes, state-dict names and method names as moe_model/model/moe/moe.py:8-245 so it is a
+drop-in for `SiglipEncoderMoELayer` / `CLIPEncoderMoELayer` / `MLPMoE` (siglip_smoe.py:108-141, builder.py:56-71):
+`experts` stays an nn.ModuleList of per-expert modules (weight upcycling writes through
+`moelayer.experts[i].load_state_dict`, llava_arch.py:115-143), `gate` stays `nn.Linear(D, E, bias=False)`.
+
+What changed underneath: `compute_moe` is one binning pass + dispatch + two grouped MFMA GEMMs + combine
+(competesmoe_amd.functional.MoEFFNModules) instead of a Python loop of E x (torch.where + gather + 2 GEMM + index_put).
+"""
+from __future__ import annotations
+
+import copy
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..functional import ExpertTable, GateLogits, MoEFFNModules, RouterSelect, DenseFFN
+from .. import ops
+
+
+def _act_code(mod) -> int:
+    """Map an activation module / callable to the kernel's activation code."""
+    name = type(mod).__name__.lower()
+    if isinstance(mod, nn.GELU):
+        return L.ACT_GELU_TANH if getattr(mod, "approximate", "none") == "tanh" else L.ACT_GELU
+    if isinstance(mod, nn.ReLU):
+        return L.ACT_RELU
+    if isinstance(mod, nn.SiLU):
+        return L.ACT_SILU
+    if isinstance(mod, nn.Identity):
+        return L.ACT_NONE
+    # transformers.activations classes (ACT2FN): GELUActivation, PytorchGELUTanh / GELUTanh, NewGELUActivation, SiLUActivation
+    if "tanh" in name or "newgelu" in name or "fastgelu" in name:
+        return L.ACT_GELU_TANH
+    if "gelu" in name:
+        return L.ACT_GELU
+    if "silu" in name or "swish" in name:
+        return L.ACT_SILU
+    if "relu" in name:
+        return L.ACT_RELU
+    fn = getattr(mod, "__name__", "")
+    if fn in ("gelu",):
+        return L.ACT_GELU
+    if fn in ("relu",):
+        return L.ACT_RELU
+    if fn in ("silu",):
+        return L.ACT_SILU
+    raise NotImplementedError(f"competesmoe_amd: unsupported expert activation {mod!r}")
+
+
+def parse_expert(expert: nn.Module) -> Tuple[nn.Linear, int, nn.Linear]:
+    """(fc1, act code, fc2) of a two-matrix expert: `Sequential(Linear, act, Linear)` (moe.py:36-38, builder.py:61-65)
+    or a module with fc1 / activation_fn / fc2 (SiglipMLP siglip_smoe.py:85-97, CLIPMLP clip_smoe.py:94-105)."""
+    if isinstance(expert, nn.Sequential) and len(expert) == 3 and isinstance(expert[0], nn.Linear) and isinstance(expert[2], nn.Linear):
+        return expert[0], _act_code(expert[1]), expert[2]
+    if hasattr(expert, "fc1") and hasattr(expert, "fc2"):
+        act = getattr(expert, "activation_fn", None) or getattr(expert, "act", None) or getattr(expert, "act_fn", None)
+        if act is None:
+            raise NotImplementedError("competesmoe_amd: expert has fc1/fc2 but no activation_fn/act attribute")
+        return expert.fc1, _act_code(act), expert.fc2
+    raise NotImplementedError(
+        f"competesmoe_amd: expert module {type(expert).__name__} is not a Linear-act-Linear FFN; the HIP path supports "
+        "nn.Sequential(Linear, act, Linear) and modules exposing fc1 / activation_fn / fc2")
+
+
+class MoeLayer(nn.Module):
+
+    def __init__(self, in_embed_dim=768, out_embed_dim=768, num_of_experts=4, num_selected=2, expert=None, args=None):
+        super().__init__()
+        self.in_embed_dim = in_embed_dim
+        self.out_embed_dim = out_embed_dim
+        self.num_of_experts = num_of_experts
+        self.num_selected = num_selected
+        self.aux_loss = {"zloss": self.zloss, "balanceloss": self.balanceloss}
+        if expert is None:
+            self.experts = nn.ModuleList([
+                nn.Sequential(nn.Linear(in_embed_dim, out_embed_dim), nn.GELU(), nn.Linear(out_embed_dim, out_embed_dim))
+                for _ in range(num_of_experts)])
+        elif isinstance(expert, nn.ModuleList):
+            self.experts = expert
+        else:
+            self.experts = nn.ModuleList([copy.deepcopy(expert) for _ in range(self.num_of_experts)])
+        self.gate = nn.Linear(in_embed_dim, num_of_experts, bias=False)
+        self.args = args
+        self.is_vision = False
+        self.log_metrics = {}
+        self._table_key = None
+        self._table = None
+
+    # ------------------------------------------------------------------ init (moe.py:50-70)
+    def init_gate_weights(self, std=0.02):
+        if getattr(self.args, "init_weight", True) is False:
+            return
+        device = self.gate.weight.device if self.gate.weight.device != torch.device("meta") else torch.device("cpu")
+        gen = torch.Generator(device=device)
+        gen.manual_seed(42)
+        nn.init.normal_(self.gate.weight, mean=0.0, std=std, generator=gen)
+        if self.gate.bias is not None:
+            nn.init.constant_(self.gate.bias, 0.0)
+
+    # ------------------------------------------------------------------ aux losses (tiny [T,E] math; moe.py:71-110, 214-226)
+    def zloss(self, gate_logits, gate_softmax=None):
+        return torch.square(torch.logsumexp(gate_logits, dim=-1)).mean()
+
+    def balanceloss(self, selected_experts, gate_softmax):
+        E = gate_softmax.shape[-1]
+        density_1_proxy = gate_softmax.mean(dim=-2)
+        one_hot = nn.functional.one_hot(selected_experts[..., 0].long(), E).float()
+        density_1 = one_hot.mean(dim=-2)
+        return (density_1_proxy * density_1).mean() * float(E ** 2)
+
+    def combine_loss(self, selected_experts, gate_softmax, gate_logits, acitve_zloss=True):
+        balance_loss = self.balanceloss(selected_experts=selected_experts, gate_softmax=gate_softmax)
+        router_z_loss = torch.tensor(0.0, device=gate_softmax.device)
+        if acitve_zloss:
+            router_z_loss = self.zloss(gate_logits, gate_softmax)
+            auxiliary_loss = balance_loss * self.args.balance_loss_coef + router_z_loss * self.args.router_z_loss_coef
+        else:
+            auxiliary_loss = balance_loss * self.args.balance_loss_coef
+        return auxiliary_loss, balance_loss, router_z_loss
+
+    def experts_diversity_loss(self, expert_outputs):
+        """moe.py:133-171 / competesmoe.py:180-218."""
+        eo = expert_outputs.to(torch.float32)
+        B, N, K, D = eo.shape
+        nrm = nn.functional.normalize(eo, p=2, dim=-1).view(B * N, K, D)
+        sim = torch.bmm(nrm, nrm.transpose(1, 2))
+        sim = sim * (1 - torch.eye(K, device=eo.device))
+        return sim.mean()
+
+    # ------------------------------------------------------------------ router (moe.py:113-132; smoe.py:42-44)
+    def gate_logits(self, x):
+        B, N, D = x.shape
+        return GateLogits.apply(x.reshape(B * N, D), self.gate.weight).view(B, N, -1)
+
+    def topk_expert(self, gate_logits, num_selected=None):
+        """Returns (weights fp32 RENORMALISED, selected_experts int32, gate_softmax fp32).  The reference returns the
+        un-normalised top-k values and divides at every call site (smoe.py:44, competesmoe.py:318); the kernel fuses
+        the division (denominator rounded to the activation dtype first, as `.to(x.dtype)` does)."""
+        K = num_selected or self.num_selected
+        shp = gate_logits.shape
+        sm, idx, w = RouterSelect.apply(gate_logits.reshape(-1, shp[-1]), K, L.SEL_SOFTMAX,
+                                        gate_logits.dtype == torch.bfloat16)
+        return w.view(*shp[:-1], K), idx.view(*shp[:-1], K), sm.view(shp)
+
+    # ------------------------------------------------------------------ expert pointer table
+    def _expert_table(self, n_experts: int, dtype, device) -> Tuple[ExpertTable, List[torch.Tensor]]:
+        parsed = [parse_expert(self.experts[i]) for i in range(n_experts)]
+        acts = {p[1] for p in parsed}
+        if len(acts) != 1:
+            raise NotImplementedError("competesmoe_amd: experts with different activations in one layer")
+        w1 = [p[0].weight for p in parsed]
+        w2 = [p[2].weight for p in parsed]
+        b1 = [p[0].bias for p in parsed]
+        b2 = [p[2].bias for p in parsed]
+        has_b1 = all(b is not None for b in b1)
+        has_b2 = all(b is not None for b in b2)
+        if (not has_b1 and any(b is not None for b in b1)) or (not has_b2 and any(b is not None for b in b2)):
+            raise NotImplementedError("competesmoe_amd: experts must all have (or all lack) a bias")
+        params = w1 + (b1 if has_b1 else []) + w2 + (b2 if has_b2 else [])
+        for p in params:
+            if p.dtype != dtype or p.device != device or not p.is_contiguous():
+                raise ValueError(f"competesmoe_amd: expert parameters must be contiguous {dtype} tensors on {device} "
+                                 f"(got {p.dtype} on {p.device}); call layer.to(x.dtype)")
+        key = tuple(p.data_ptr() for p in params)
+        if key != self._table_key:
+            F_, D_ = w1[0].shape
+            Dout = w2[0].shape[0]
+            self._table = ExpertTable(
+                E=n_experts, D=D_, F=F_, Dout=Dout, layout=L.B_NK, act=acts.pop(),
+                w1_ptrs=ops.ptr_array(w1, device), w2_ptrs=ops.ptr_array(w2, device),
+                b1_ptrs=ops.ptr_array(b1, device) if has_b1 else None,
+                b2_ptrs=ops.ptr_array(b2, device) if has_b2 else None, param_dtype=dtype)
+            self._table_key = key
+        return self._table, params
+
+    # ------------------------------------------------------------------ dispatch + FFN + combine (moe.py:172-213)
+    def compute_moe(self, selected_experts, weights, results, x, expert_outputs=None, return_topk_outputs=False,
+                    n_experts: Optional[int] = None, weights_rounded: bool = False):
+        """out[b,t] = sum_k w[b,t,k] * expert_{idx[b,t,k]}(x[b,t]) with the reference's accumulation order/rounding.
+        `results` is accepted for signature compatibility (the reference accumulates into it; callers pass zeros)."""
+        B, N, D = x.shape
+        n_experts = n_experts or len(self.experts)
+        tab, params = self._expert_table(n_experts, x.dtype, x.device)
+        mode = L.COMBINE_SEQ_RW if weights_rounded else L.COMBINE_SEQ
+        idx2 = selected_experts.reshape(B * N, -1)
+        if idx2.dtype != torch.int32:
+            idx2 = idx2.int()
+        w2 = weights.reshape(B * N, -1)
+        if w2.dtype != torch.float32:
+            w2 = w2.float()
+        out = MoEFFNModules.apply(x.reshape(B * N, D), w2.contiguous(), idx2.contiguous(), tab, mode, *params)
+        return out.view(B, N, -1)
+
+    def dense_expert(self, i: int, x):
+        """experts[i](x) over all tokens (shared expert / competition pass)."""
+        fc1, act, fc2 = parse_expert(self.experts[i])
+        B, N, D = x.shape
+        y = DenseFFN.apply(x.reshape(B * N, D), fc1.weight, fc1.bias, fc2.weight, fc2.bias, act, L.B_NK)
+        return y.view(B, N, -1)
+
+    def forward(self, x, return_id_experts=False):
+        gate_logits = self.gate_logits(x)
+        weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
+        output = self.compute_moe(selected_experts, weights, None, x)
+        auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(selected_experts, gate_softmax, gate_logits)
+        infor_aux = {"balance_loss": balance_loss.clone().detach(), "router_z_loss": router_z_loss.clone().detach()}
+        if return_id_experts:
+            return output, auxiliary_loss, gate_softmax
+        return output, auxiliary_loss, None, infor_aux

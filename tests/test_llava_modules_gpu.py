@@ -1,0 +1,168 @@
+"""GPU parity of the LLaVA-stack layers (HIP path) against the golden vectors captured from the reference.
+
+Tolerances (written here, as the task statement asks): fp32 outputs/grads <= 1e-5 (max error relative to max |ref|);
+bf16 <= 1e-3 relative L2 AND <= 2 bf16 ulp of max|ref| elementwise -- the HIP path reproduces the reference's rounding
+sequence, so only fp32 accumulation-order noise flips a few roundings; router indices bit-exact on rows without a tie."""
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+
+from tests.golden_util import load, args_of, rel_l2, max_rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+if torch.cuda.is_available():
+    from competesmoe_amd.moe import get_moe
+
+
+class TanhMLP(nn.Module):
+    """fc1 / activation_fn / fc2 expert (the shape of SiglipMLP, siglip_smoe.py:85-97)."""
+    def __init__(self, D, F):
+        super().__init__()
+        self.activation_fn = nn.GELU(approximate="tanh")
+        self.fc1 = nn.Linear(D, F)
+        self.fc2 = nn.Linear(F, D)
+
+    def forward(self, x):
+        return self.fc2(self.activation_fn(self.fc1(x)))
+
+
+def build_layer(fx):
+    m = fx["meta"]
+    args = args_of(fx)
+    D, F, Dout, E, K = m["D"], m["F"], m["Dout"], m["E"], m["K"]
+    if m["expert_kind"] == "seq_gelu":
+        mk = lambda: nn.Sequential(nn.Linear(D, F), nn.GELU(), nn.Linear(F, Dout))
+    else:
+        mk = lambda: TanhMLP(D, F)
+    cls = get_moe(m["moe_name"])
+    if m["moe_name"] in ("smoe_share", "deepseekv3"):
+        layer = cls(D, Dout, E, K, mk(), args)
+    else:
+        layer = cls(D, Dout, E, K, nn.ModuleList([mk() for _ in range(E)]), args)
+    state = dict(fx["state"])
+    flips = state.pop("prob_flips", None)
+    missing, unexpected = layer.load_state_dict(state, strict=False)
+    assert not unexpected and set(missing) <= {"prob_flips"}, (missing, unexpected)
+    dt = torch.float32 if m["dtype"] == "float32" else torch.bfloat16
+    layer = layer.to(DEV).to(dt).train()
+    if flips is not None:
+        layer.total_steps, layer.step_warm, layer.flip_steps = 10, 0, 10
+        layer.prob_flips = fx["prob_flips"].to(DEV)
+        layer.set_current_steps(3)
+    return layer, dt
+
+
+def tols(dt):
+    return (1e-5, 1e-5) if dt == torch.float32 else (1e-3, 2 * 2 ** -8)
+
+
+CASES = ["smoe", "smoe_siglip", "smoe_proj", "competesmoe_router", "competesmoe_comp", "competesmoe_comp_hybrid",
+         "smoe_share", "deepseekv3"]
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CASES)
+def test_layer_matches_reference_golden(case, tag):
+    fx = load(f"llava_{case}_{tag}")
+    layer, dt = build_layer(fx)
+    rl, mr = tols(dt)
+    x = fx["x"].to(DEV).requires_grad_(True)
+    dy = fx["dy"].to(DEV)
+
+    # --- router stage: logits / softmax / indices / weights
+    with torch.no_grad():
+        lg = layer.gate_logits(fx["x"].to(DEV))
+        w, idx, sm = layer.topk_expert(lg)
+    glg = fx["gate_logits"].to(DEV)
+    assert max_rel(lg, glg) <= (1e-5 if dt == torch.float32 else 2 ** -7)
+    # indices: bit-exact given identical logits; when the HIP logits differ from the CPU ones by an ulp, compare on the
+    # reference's logits instead (the selection kernel itself must be exact)
+    from competesmoe_amd import ops, _lib as L
+    K = idx.shape[-1]
+    sm2, idx2, w2 = ops.router_select(glg.reshape(-1, glg.shape[-1]).contiguous(), K, L.SEL_SOFTMAX, dt == torch.bfloat16)
+    gi = fx["selected_experts"].to(DEV).reshape(-1, K)
+    mism = (idx2.long() != gi).any(-1)
+    if mism.any():   # only exact ties (torch.topk's CPU tie order is unspecified)
+        gsm = fx["gate_softmax"].to(DEV).reshape(-1, glg.shape[-1])
+        a = torch.gather(gsm, -1, idx2.long())[mism].sort(-1).values
+        b = torch.gather(gsm, -1, gi)[mism].sort(-1).values
+        assert torch.equal(a, b)
+        assert int(mism.sum()) <= 4
+    ok = ~mism
+    assert torch.allclose(sm2, fx["gate_softmax"].to(DEV).reshape(sm2.shape), rtol=3e-6, atol=1e-8)
+    assert torch.allclose(w2[ok], fx["weights"].to(DEV).reshape(-1, K)[ok], rtol=2e-6, atol=1e-8)
+
+    # --- full forward / backward
+    out, aux, none, infor = layer(x)
+    assert none is None and out.dtype == dt and out.shape == fx["output"].shape
+    rows_ok = torch.ones(out.shape[0] * out.shape[1], dtype=torch.bool, device=DEV)
+    with torch.no_grad():
+        # rows whose routing differs from the reference (ulp-level logit differences at a near-tie) are excluded
+        # from the elementwise output check and counted
+        live_idx = layer.topk_expert(layer.gate_logits(fx["x"].to(DEV)))[1].reshape(-1, K)
+        if not fx["meta"]["competition"]:
+            rows_ok = (live_idx.long() == gi).all(-1)
+    assert int((~rows_ok).sum()) <= 2
+    o = out.detach().reshape(-1, out.shape[-1])[rows_ok]
+    g = fx["output"].to(DEV).reshape(-1, out.shape[-1])[rows_ok]
+    assert rel_l2(o, g) <= rl, rel_l2(o, g)
+    assert max_rel(o, g) <= mr, max_rel(o, g)
+    assert abs(float(aux) - float(fx["aux_loss"])) <= (2e-5 if dt == torch.float32 else 2e-3) * max(1.0, abs(float(fx["aux_loss"])))
+    assert set(infor) == set(fx["infor_aux"])
+    for k, v in fx["infor_aux"].items():
+        assert abs(float(infor[k]) - float(v)) <= (2e-5 if dt == torch.float32 else 5e-3) * max(1e-2, abs(float(v))), k
+
+    ((out.float() * dy.float()).sum() + aux.float()).backward()
+    if bool(rows_ok.all()):
+        gl = 4 * rl
+        assert rel_l2(x.grad, fx["x_grad"].to(DEV)) <= gl, rel_l2(x.grad, fx["x_grad"].to(DEV))
+        for name, p in layer.named_parameters():
+            gg = fx["grads"].get(name)
+            if gg is None:
+                continue
+            assert p.grad is not None, name
+            assert rel_l2(p.grad, gg.to(DEV)) <= gl, (name, rel_l2(p.grad, gg.to(DEV)))
+
+    # --- no-grad forward: aux is zero, same output
+    with torch.no_grad():
+        out_e, aux_e, _, infor_e = layer(fx["x"].to(DEV))
+    if fx["meta"]["moe_name"] != "deepseekv3":
+        assert float(aux_e) == 0.0 and infor_e == {}
+    oe = out_e.reshape(-1, out.shape[-1])[rows_ok] if not fx["meta"]["competition"] else out_e.reshape(-1, out.shape[-1])
+    ge = fx["output_nograd"].to(DEV).reshape(-1, out.shape[-1])
+    ge = ge[rows_ok] if not fx["meta"]["competition"] else ge
+    assert rel_l2(oe, ge) <= max(rl, 1e-5)
+
+
+def test_registry_and_errors():
+    from competesmoe_amd.moe import MOE_REGISTRY, register_moe
+    assert {"smoe", "competesmoe", "smoe_share", "deepseekv3"} <= set(MOE_REGISTRY)
+    with pytest.raises(ValueError):
+        get_moe("nope")
+    with pytest.raises(ValueError):
+        get_moe("competesmoe")(8, 8, 2, 1, None, types.SimpleNamespace())     # missing rate_flip / warm_up
+    layer = get_moe("competesmoe")(8, 8, 2, 1, None, types.SimpleNamespace(rate_flip=0.5, warm_up=1.0, max_compete_in_iter=1))
+    with pytest.raises(ValueError):
+        layer.set_total_steps(10, 0, {})        # flip_steps <= 0
+    with pytest.raises(AssertionError):
+        layer.set_total_steps(10, None, {})
+
+
+def test_schedule_matches_reference_golden():
+    fx = load("llava_schedule")
+    a = types.SimpleNamespace(**fx["meta"]["args"])
+    cls = get_moe("competesmoe")
+    layers = [cls(16, 16, 4, 2, None, a) for _ in range(4)]    # CPU modules: schedule is host logic
+    # the reference draws from the CUDA generator when a GPU is visible; goldens were drawn on CPU -> compare structure
+    torch.manual_seed(fx["meta"]["seed"])
+    final = {}
+    for i, l in enumerate(layers):
+        final = l.set_total_steps(fx["meta"]["total_steps"], i, final)
+    freq = sum(v.int().cpu() for v in final.values())
+    assert int(freq.max()) <= a.max_compete_in_iter
+    assert layers[0].step_warm == fx["step_warm"] and layers[0].flip_steps == fx["flip_steps"]
+    assert layers[2].prob_flips.shape == (fx["flip_steps"],)
