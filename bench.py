@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- MoE-layer forward+backward tokens/s on MI355X (BASELINE.json metric).
+
+One "step" = one forward + backward of ONE sparse-MoE layer (router -> bin -> dispatch -> grouped expert GEMMs ->
+combine, and the whole backward incl. expert weight gradients) over one batch of synthetic tokens resident in HBM.
+
+Workload at N=1 (BASELINE.json configs[1]): T=32768 tokens as [16, 2048], d_model=4096, d_ff=11008, 64 experts, top-2,
+bf16, experts Linear(D,F)+b -> GELU -> Linear(F,D)+b, `smoe` routing; x ~ N(0,1) seed 0, gate N(0,0.02) generator-seed
+42, expert weights N(0,0.02) seed 1, upstream gradient N(0,1) seed 2.
+N>1: expert-parallel (competesmoe_amd.ep): experts sharded E/N per rank, T tokens PER RANK (weak scaling), RCCL
+all-to-all over xGMI for dispatch/combine; launched by torch.distributed.run, one rank per GPU.
+
+Prints ONE JSON line on rank 0 (see the driver contract): value = total tokens / max-over-ranks time of K steps.
+`roofline` is for the dominant kernel (the grouped expert GEMM family): algorithmic FLOPs per launch / mean launch
+duration from HIP events recorded on the launch stream inside the timed region.  `cpu_baseline` times the CPU oracle
+(oracle/moe_oracle.py, a port of the reference layer) on a bounded sample on this host's cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tokens", type=int, default=32768)
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--d-model", type=int, default=4096)
+    ap.add_argument("--d-ff", type=int, default=11008)
+    ap.add_argument("--experts", type=int, default=64)
+    ap.add_argument("--topk", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--skew", action="store_true", help="add +2.0 to 8 gate rows (Zipf-like load, BASELINE.md)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=2048)
+    return ap.parse_args()
+
+
+def make_layer(a, dev, dt, E_local=None, seed=1):
+    from competesmoe_amd.moe import get_moe
+    D, F, E, K = a.d_model, a.d_ff, a.experts, a.topk
+    args = types.SimpleNamespace(balance_loss_coef=0.01, router_z_loss_coef=0.001)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    with torch.device(dev):
+        experts = nn.ModuleList([nn.Sequential(nn.Linear(D, F, dtype=dt), nn.GELU(), nn.Linear(F, D, dtype=dt))
+                                 for _ in range(E if E_local is None else E_local)])
+    with torch.no_grad():
+        for m in experts:
+            for p in m.parameters():
+                p.normal_(0.0, 0.02, generator=g)
+    if E_local is None:
+        layer = get_moe("smoe")(D, D, E, K, experts, args)
+    else:
+        from competesmoe_amd.ep import EPSMoeLayer
+        layer = EPSMoeLayer(D, D, E, K, experts, args)
+    layer = layer.to(dev).to(dt).train()
+    if a.skew:
+        with torch.no_grad():
+            layer.gate.weight[:8] += 2.0 / (D ** 0.5)
+    return layer
+
+
+def cpu_baseline(a):
+    """CPU oracle (port of the reference layer) on a bounded sample: same D/F/E/K, fp32, `cpu_tokens` tokens."""
+    from oracle import moe_oracle as O
+    D, F, E, K, T = a.d_model, a.d_ff, a.experts, a.topk, a.cpu_tokens
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1)
+    w1 = torch.empty(F, D).normal_(0, 0.02, generator=g)
+    w2 = torch.empty(D, F).normal_(0, 0.02, generator=g)
+    experts = []
+    for _ in range(E):   # clones of one random draw: same arithmetic/traffic as independent weights, faster to set up
+        experts.append(tuple(t.requires_grad_(True) for t in (w1.clone(), torch.zeros(F), w2.clone(), torch.zeros(D))))
+    wg = torch.empty(E, D).normal_(0, 0.02, generator=torch.Generator().manual_seed(42)).requires_grad_(True)
+    x = torch.randn(1, T, D, generator=torch.Generator().manual_seed(0)).requires_grad_(True)
+    dy = torch.randn(1, T, D, generator=torch.Generator().manual_seed(2))
+    args = types.SimpleNamespace(balance_loss_coef=0.01, router_z_loss_coef=0.001)
+    t0 = time.perf_counter()
+    out, aux, _, _ = O.llava_smoe_forward(x, wg, experts, "gelu", K, args)
+    torch.autograd.backward([out, aux], [dy, torch.ones(())])
+    dt_s = time.perf_counter() - t0
+    return {"value": T / dt_s, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (fp32 port of the reference SMoE layer), one fwd+bwd of {T} tokens, D={D} F={F} E={E} K={K}, "
+                      f"{dt_s:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            print(f"bench.py: --gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} ...`", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from competesmoe_amd import ops
+    T, D = a.tokens, a.d_model
+    Bsz = max(1, T // a.seq)
+    Nseq = T // Bsz
+    if world > 1:
+        assert a.experts % world == 0, "experts must divide over ranks"
+        layer = make_layer(a, dev, dt, E_local=a.experts // world, seed=1 + rank)
+    else:
+        layer = make_layer(a, dev, dt)
+    x = torch.randn(Bsz, Nseq, D, device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(rank)).to(dt)
+    dy = torch.randn(Bsz, Nseq, D, device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(2 + rank)).to(dt)
+    x.requires_grad_(True)
+    one = torch.ones((), device=dev)
+
+    def step():
+        for p in layer.parameters():
+            p.grad = None
+        x.grad = None
+        out, aux, _, _ = layer(x)
+        torch.autograd.backward([out, aux.float()], [dy, one])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt)
+    ms = el / a.steps * 1e3
+    total_tokens = Bsz * Nseq * world
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family (grouped expert GEMM): FLOPs per launch / mean launch duration
+        gemm = {k: v for k, v in prof.items() if k.startswith("grouped_gemm") or k.startswith("grouped_wgrad")}
+        detail = {}
+        for k, v in prof.items():
+            if k in gemm:
+                detail[k] = {"calls_per_step": v["calls"] / a.steps, "ms": round(v["ms"], 4),
+                             "TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1)}
+            else:
+                detail[k] = {"calls_per_step": v["calls"] / a.steps, "ms": round(v["ms"], 4),
+                             "GB/s": round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1)}
+        roof = None
+        if gemm:
+            dom = max(gemm, key=lambda k: gemm[k]["ms"] * gemm[k]["calls"])
+            ach = gemm[dom]["work"] / (gemm[dom]["ms"] * 1e-3) / 1e12
+            peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else 157.3
+            tot_ms = sum(v["ms"] * v["calls"] for v in gemm.values()) / a.steps
+            tot_fl = sum(v["work"] * v["calls"] for v in gemm.values()) / a.steps
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "all_grouped_gemm": {"ms_per_step": round(tot_ms, 3), "TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
+                                         "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4)},
+                    "hbm_kernels": {k: {"GB/s": d["GB/s"], "frac": round(d["GB/s"] / HBM_PEAK_GBS, 4)}
+                                    for k, d in detail.items() if "GB/s" in d}}
+        res = {
+            "metric": "MoE-layer fwd+bwd tokens/sec at d_model=4096, 64 experts top-2", "value": round(total_tokens / el, 1),
+            "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"single sparse-MoE layer (smoe routing), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
+                                   f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, Linear+bias/GELU experts, "
+                                   f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
+                       "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
+                       "parallelism": "single GPU" if world == 1 else f"ep{world} (experts sharded, RCCL all-to-all)"},
+            "roofline": roof, "kernels": detail,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(a)
+            except Exception as e:   # the GPU number stands even if the host cannot hold the CPU sample
+                res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,46 @@ from . import _lib as L
 
 lib = L.lib
 
+# ---- optional per-launch HIP-event timing (bench.py): events are recorded on the launch stream around every C call ----
+_PROFILE = None   # None, or dict name -> list[(start_event, end_event, work)]
+
+
+def profile_start():
+    global _PROFILE
+    _PROFILE = {}
+
+
+def profile_stop():
+    """Returns {name: {"calls": n, "ms": mean launch duration, "work": mean algorithmic work units}} (synchronises)."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, evs in (rec or {}).items():
+        ms = [a.elapsed_time(b) for a, b, _ in evs]
+        out[name] = {"calls": len(ms), "ms": sum(ms) / len(ms), "work": sum(w for _, _, w in evs) / len(evs)}
+    return out
+
+
+class _timed:
+    __slots__ = ("name", "work", "a")
+
+    def __init__(self, name, work=0.0):
+        self.name, self.work, self.a = name, work, None
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.a is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _PROFILE.setdefault(self.name, []).append((self.a, b, self.work))
+        return False
+
 
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
@@ -44,7 +84,8 @@ def gate_logits(x2: torch.Tensor, w_gate: torch.Tensor) -> torch.Tensor:
     T, D = x2.shape
     E = w_gate.shape[0]
     out = torch.empty(T, E, dtype=x2.dtype, device=x2.device)
-    L.check(lib.csmoe_gate_logits(x2.data_ptr(), w_gate.data_ptr(), out.data_ptr(), T, D, E, _dt(x2), _stream()), "gate_logits")
+    with _timed("gate_logits", T * D * x2.element_size()):
+        L.check(lib.csmoe_gate_logits(x2.data_ptr(), w_gate.data_ptr(), out.data_ptr(), T, D, E, _dt(x2), _stream()), "gate_logits")
     return out
 
 
@@ -100,16 +141,18 @@ def bin_tokens(idx: torch.Tensor, E: int) -> Bins:
 def dispatch_rows(x2: torch.Tensor, bins: Bins) -> torch.Tensor:
     T, D = x2.shape
     xs = torch.empty(bins.n, D, dtype=x2.dtype, device=x2.device)
-    L.check(lib.csmoe_dispatch_rows(x2.data_ptr(), bins.perm.data_ptr(), bins.K, xs.data_ptr(), bins.n, D, _dt(x2), _stream()),
-            "dispatch_rows")
+    with _timed("dispatch_rows", (T + bins.n) * D * x2.element_size()):     # read D, write K*D per token
+        L.check(lib.csmoe_dispatch_rows(x2.data_ptr(), bins.perm.data_ptr(), bins.K, xs.data_ptr(), bins.n, D, _dt(x2), _stream()),
+                "dispatch_rows")
     return xs
 
 
 def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
     D = dxs.shape[1]
     dx = torch.empty(T, D, dtype=dxs.dtype, device=dxs.device)
-    L.check(lib.csmoe_dispatch_rows_bwd(dxs.data_ptr(), bins.slot_of.data_ptr(), bins.K, _ptr(add), dx.data_ptr(), T, D,
-                                        _dt(dxs), _stream()), "dispatch_rows_bwd")
+    with _timed("dispatch_rows_bwd", (T + bins.n) * D * dxs.element_size()):
+        L.check(lib.csmoe_dispatch_rows_bwd(dxs.data_ptr(), bins.slot_of.data_ptr(), bins.K, _ptr(add), dx.data_ptr(), T, D,
+                                            _dt(dxs), _stream()), "dispatch_rows_bwd")
     return dx
 
 
@@ -117,8 +160,9 @@ def combine(y: torch.Tensor, bins: Bins, idx: torch.Tensor, w: torch.Tensor, mod
             obias: Optional[torch.Tensor] = None) -> torch.Tensor:
     D = y.shape[1]
     out = torch.empty(T, D, dtype=y.dtype, device=y.device)
-    L.check(lib.csmoe_combine(y.data_ptr(), bins.slot_of.data_ptr(), _ptr(idx), w.data_ptr(), _ptr(obias), out.data_ptr(),
-                              T, bins.K, D, _dt(y), mode, _stream()), "combine")
+    with _timed("combine", (T + bins.n) * D * y.element_size() + bins.n * 4):
+        L.check(lib.csmoe_combine(y.data_ptr(), bins.slot_of.data_ptr(), _ptr(idx), w.data_ptr(), _ptr(obias), out.data_ptr(),
+                                  T, bins.K, D, _dt(y), mode, _stream()), "combine")
     return out
 
 
@@ -126,8 +170,9 @@ def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: to
     T, D = dout.shape
     dy = torch.empty(bins.n, D, dtype=dout.dtype, device=dout.device)
     dw = torch.empty(T, bins.K, dtype=torch.float32, device=dout.device) if (want_dw and y is not None) else None
-    L.check(lib.csmoe_combine_bwd(dout.data_ptr(), _ptr(y), bins.perm.data_ptr(), bins.slot_of.data_ptr(), w.data_ptr(),
-                                  dy.data_ptr(), _ptr(dw), T, bins.K, D, _dt(dout), _stream()), "combine_bwd")
+    with _timed("combine_bwd", (T + bins.n * (2 if y is not None else 1)) * D * dout.element_size()):
+        L.check(lib.csmoe_combine_bwd(dout.data_ptr(), _ptr(y), bins.perm.data_ptr(), bins.slot_of.data_ptr(), w.data_ptr(),
+                                      dy.data_ptr(), _ptr(dw), T, bins.K, D, _dt(dout), _stream()), "combine_bwd")
     return dy, dw
 
 
@@ -138,9 +183,10 @@ def grouped_gemm(A: torch.Tensor, b_ptrs: torch.Tensor, b_layout: int, ldb: int,
     M, Kd = A.shape
     Cm = torch.empty(M, N, dtype=A.dtype, device=A.device)
     C2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c2 else None
-    L.check(lib.csmoe_grouped_gemm(A.data_ptr(), A.stride(0), b_ptrs.data_ptr(), b_layout, ldb, _ptr(bias_ptrs),
-                                   offsets.data_ptr(), E, M, N, Kd, Cm.data_ptr(), _ptr(C2), _ptr(aux), N, epilogue, act,
-                                   _dt(A), int(force_generic), _stream()), "grouped_gemm")
+    with _timed("grouped_gemm_" + ("nt" if b_layout == L.B_NK else "nn"), 2.0 * M * N * Kd):
+        L.check(lib.csmoe_grouped_gemm(A.data_ptr(), A.stride(0), b_ptrs.data_ptr(), b_layout, ldb, _ptr(bias_ptrs),
+                                       offsets.data_ptr(), E, M, N, Kd, Cm.data_ptr(), _ptr(C2), _ptr(aux), N, epilogue, act,
+                                       _dt(A), int(force_generic), _stream()), "grouped_gemm")
     return (Cm, C2) if want_c2 else Cm
 
 
@@ -162,9 +208,10 @@ def grouped_wgrad(A: torch.Tensor, B: torch.Tensor, offsets: torch.Tensor, E: in
     """out[e] = A_e^T @ B_e for every expert; `out` is [E, Na, Nb] (or any buffer the pointers index)."""
     M, Na = A.shape
     Nb = B.shape[1]
-    L.check(lib.csmoe_grouped_wgrad(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), offsets.data_ptr(), E, M, Na, Nb,
-                                    out_ptrs.data_ptr(), Nb, _dt(A), _dt(out), int(accumulate), int(force_generic), _stream()),
-            "grouped_wgrad")
+    with _timed("grouped_wgrad_tn", 2.0 * M * Na * Nb):
+        L.check(lib.csmoe_grouped_wgrad(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), offsets.data_ptr(), E, M, Na, Nb,
+                                        out_ptrs.data_ptr(), Nb, _dt(A), _dt(out), int(accumulate), int(force_generic), _stream()),
+                "grouped_wgrad")
     return out
 
 
@@ -179,8 +226,9 @@ def dense_wgrad(A: torch.Tensor, B: torch.Tensor, out_dtype=None, force_generic:
 
 def grouped_colsum(G: torch.Tensor, offsets: torch.Tensor, E: int, out: torch.Tensor, out_ptrs: torch.Tensor):
     M, N = G.shape
-    L.check(lib.csmoe_grouped_colsum(G.data_ptr(), G.stride(0), offsets.data_ptr(), E, N, out_ptrs.data_ptr(), _dt(G), _dt(out),
-                                     _stream()), "grouped_colsum")
+    with _timed("grouped_colsum", M * N * G.element_size()):
+        L.check(lib.csmoe_grouped_colsum(G.data_ptr(), G.stride(0), offsets.data_ptr(), E, N, out_ptrs.data_ptr(), _dt(G), _dt(out),
+                                         _stream()), "grouped_colsum")
     return out
 
 

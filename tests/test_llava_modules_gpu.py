@@ -106,7 +106,26 @@ def test_layer_matches_reference_golden(case, tag):
         live_idx = layer.topk_expert(layer.gate_logits(fx["x"].to(DEV)))[1].reshape(-1, K)
         if not fx["meta"]["competition"]:
             rows_ok = (live_idx.long() == gi).all(-1)
-    assert int((~rows_ok).sum()) <= 2
+        else:
+            # competition: routing = top-K of the mean-softplus affinities, computed in x.dtype.  In bf16 those are
+            # 8-bit values with frequent (near-)ties: rows whose selection differs from the
+            # reference's must be within one bf16 ulp of a tie; they are excluded from the elementwise check.
+            aw, aidx, asm, aff, _ = layer.competition_policy(fx["x"].to(DEV))
+            ga = fx["aff_scores"].to(DEV).reshape(-1, aff.shape[-1]).float()
+            assert max_rel(aff.reshape(ga.shape), ga) <= (1e-5 if dt == torch.float32 else 2 ** -7)
+            gai = fx["aff_selected"].to(DEV).reshape(-1, K)
+            rows_ok = (aidx.reshape(-1, K).long() == gai).all(-1)
+            bad = ~rows_ok
+            if dt == torch.float32:
+                assert not bad.any()
+            else:
+                assert bad.float().mean() <= 0.10, bad.float().mean()
+                if bad.any():
+                    a = torch.gather(ga, -1, aidx.reshape(-1, K).long())[bad].sort(-1).values
+                    b = torch.gather(ga, -1, gai)[bad].sort(-1).values
+                    assert ((a - b).abs() <= 2 ** -7 * b.abs()).all()
+    if not fx["meta"]["competition"]:
+        assert int((~rows_ok).sum()) <= 2
     o = out.detach().reshape(-1, out.shape[-1])[rows_ok]
     g = fx["output"].to(DEV).reshape(-1, out.shape[-1])[rows_ok]
     assert rel_l2(o, g) <= rl, rel_l2(o, g)
@@ -132,10 +151,11 @@ def test_layer_matches_reference_golden(case, tag):
         out_e, aux_e, _, infor_e = layer(fx["x"].to(DEV))
     if fx["meta"]["moe_name"] != "deepseekv3":
         assert float(aux_e) == 0.0 and infor_e == {}
-    oe = out_e.reshape(-1, out.shape[-1])[rows_ok] if not fx["meta"]["competition"] else out_e.reshape(-1, out.shape[-1])
-    ge = fx["output_nograd"].to(DEV).reshape(-1, out.shape[-1])
-    ge = ge[rows_ok] if not fx["meta"]["competition"] else ge
-    assert rel_l2(oe, ge) <= max(rl, 1e-5)
+    with torch.no_grad():
+        ok_e = (layer.topk_expert(layer.gate_logits(fx["x"].to(DEV)))[1].reshape(-1, K).long() == gi).all(-1)
+    oe = out_e.reshape(-1, out.shape[-1])[ok_e]
+    ge = fx["output_nograd"].to(DEV).reshape(-1, out.shape[-1])[ok_e]
+    assert int((~ok_e).sum()) <= 2 and rel_l2(oe, ge) <= max(rl, 1e-5)
 
 
 def test_registry_and_errors():
