@@ -183,7 +183,7 @@ def main():
                     "hbm_kernels": {k: {"GB/s": d["GB/s"], "frac": round(d["GB/s"] / HBM_PEAK_GBS, 4)}
                                     for k, d in detail.items() if "GB/s" in d}}
         res = {
-            "metric": "MoE-layer fwd+bwd tokens/sec at d_model=4096, 64 experts top-2", "value": round(total_tokens / el, 1),
+            "metric": "MoE-layer fwd+bwd tokens/sec at d_model=4096, 64 experts top-2", "value": round(total_tokens * a.steps / el, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"single sparse-MoE layer (smoe routing), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "

@@ -130,10 +130,13 @@ def test_layer_matches_reference_golden(case, tag):
     g = fx["output"].to(DEV).reshape(-1, out.shape[-1])[rows_ok]
     assert rel_l2(o, g) <= rl, rel_l2(o, g)
     assert max_rel(o, g) <= mr, max_rel(o, g)
-    assert abs(float(aux) - float(fx["aux_loss"])) <= (2e-5 if dt == torch.float32 else 2e-3) * max(1.0, abs(float(fx["aux_loss"])))
+    # scalars: when a few bf16-competition rows route differently (near-ties, see above) the losses that average over
+    # the selected experts (diversity, balance) move with them -> tolerance widened by the differing-row fraction
+    slack = float((~rows_ok).float().mean()) if fx["meta"]["competition"] else 0.0
+    assert abs(float(aux) - float(fx["aux_loss"])) <= ((2e-5 if dt == torch.float32 else 2e-3) + slack) * max(1.0, abs(float(fx["aux_loss"])))
     assert set(infor) == set(fx["infor_aux"])
     for k, v in fx["infor_aux"].items():
-        assert abs(float(infor[k]) - float(v)) <= (2e-5 if dt == torch.float32 else 5e-3) * max(1e-2, abs(float(v))), k
+        assert abs(float(infor[k]) - float(v)) <= ((2e-5 if dt == torch.float32 else 5e-3) + 2 * slack) * max(1e-2, abs(float(v))), k
 
     ((out.float() * dy.float()).sum() + aux.float()).backward()
     if bool(rows_ok.all()):
