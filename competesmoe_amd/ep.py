@@ -1,0 +1,180 @@
+"""Expert parallelism for the sparse-MoE layer: experts sharded over the ranks of one node, tokens exchanged with RCCL
+all-to-all over xGMI.
+
+The reference has NO expert parallelism (data parallel only); this is the multi-GPU form BASELINE.json's
+north_star asks for, with one correctness contract: the same numbers as the single-GPU layer on the same tokens.
+
+Layout: rank r owns the contiguous experts [r*E/P, (r+1)*E/P).  Because the binned row space is sorted by GLOBAL expert id,
+the rows a rank must send to peer p are one contiguous slice -> `all_to_all_single` with per-peer split sizes, no packing
+pass.  On the full xGMI mesh every peer pair has its own link, so an all-to-all uses all 7 links at once (ring collectives
+would be bound by one).  Per forward: one tiny all-to-all of per-expert counts (+ one D2H read of 2*P*E/P ints: torch's
+collective API wants host split sizes), then rows out, rows back; backward mirrors with the same splits.
+
+Received rows arrive grouped by source rank; a second (local, K=1) binning pass regroups them by local expert for the
+grouped GEMM and is undone before the return trip.
+
+Everything that touches `torch.distributed` is in the small functions at the top so the plumbing is testable with `gloo`
+on CPU (tests/test_ep_gloo.py); the compute between the exchanges is the same HIP kernels as the single-GPU path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .functional import ExpertTable, _flip
+from .moe.moe import MoeLayer
+from .moe.register import register_moe
+
+
+# ------------------------------------------------------------------------------------------------ plumbing (gloo-testable)
+@dataclass
+class EPPlan:
+    P: int
+    E_local: int
+    send_splits: List[int]        # rows this rank sends to each peer
+    recv_splits: List[int]        # rows this rank receives from each peer
+    recv_counts: torch.Tensor     # [P, E_local] int32 (device): rows from peer s for local expert e
+    R: int                        # total rows received
+
+
+def make_plan(counts: torch.Tensor, group=None) -> EPPlan:
+    """counts[E] (int32, device) = rows per GLOBAL expert on this rank -> exchange plan.  One small all-to-all + one host read."""
+    P = dist.get_world_size(group)
+    E = counts.numel()
+    assert E % P == 0, "experts must divide evenly over the expert-parallel ranks"
+    El = E // P
+    send = counts.view(P, El).contiguous()
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    both = torch.stack([send.sum(1), recv.sum(1)]).cpu()       # the one device->host sync of the exchange
+    send_splits = [int(v) for v in both[0]]
+    recv_splits = [int(v) for v in both[1]]
+    return EPPlan(P, El, send_splits, recv_splits, recv, sum(recv_splits))
+
+
+def a2a_rows(rows: torch.Tensor, in_splits: List[int], out_splits: List[int], group=None) -> torch.Tensor:
+    """Variable-size row exchange: peer p gets rows[sum(in[:p]) : sum(in[:p+1])]."""
+    out = torch.empty(sum(out_splits), rows.shape[1], dtype=rows.dtype, device=rows.device)
+    dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    return out
+
+
+def local_expert_ids(plan: EPPlan) -> torch.Tensor:
+    """Local expert id of every received row (rows arrive grouped by source rank, sorted by expert inside a group)."""
+    dev = plan.recv_counts.device
+    pattern = torch.arange(plan.E_local, device=dev, dtype=torch.int32).repeat(plan.P)
+    return torch.repeat_interleave(pattern, plan.recv_counts.flatten().long(), output_size=plan.R)
+
+
+# ------------------------------------------------------------------------------------------------ the EP FFN
+class _Unsort:
+    """Adapter so ops.dispatch_rows can apply the inverse of a K=1 binning (out[m] = sorted[slot_of[m]])."""
+    def __init__(self, bins):
+        self.perm, self.K, self.n = bins.slot_of, 1, bins.n
+
+
+class EPFFN(torch.autograd.Function):
+    """dispatch -> all-to-all -> local grouped FFN -> all-to-all -> combine, and the mirrored backward."""
+
+    @staticmethod
+    def forward(ctx, x2, w, idx, tab: ExpertTable, E_global: int, group, combine_mode: int, *params):
+        x2 = x2.contiguous()
+        T = x2.shape[0]
+        bins = ops.bin_tokens(idx, E_global)
+        xs = ops.dispatch_rows(x2, bins)
+        plan = make_plan(bins.counts, group)
+        recv = a2a_rows(xs, plan.send_splits, plan.recv_splits, group)
+        lb = ops.bin_tokens(local_expert_ids(plan).view(-1, 1), tab.E)
+        rs = ops.dispatch_rows(recv, lb)
+        hpre, hact = ops.grouped_gemm(rs, tab.w1_ptrs, tab.layout, tab.D, tab.F, lb.offsets, tab.E, bias_ptrs=tab.b1_ptrs,
+                                      epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True)
+        ys = ops.grouped_gemm(hact, tab.w2_ptrs, tab.layout, tab.F, tab.Dout, lb.offsets, tab.E, bias_ptrs=tab.b2_ptrs,
+                              epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
+        y = a2a_rows(ops.dispatch_rows(ys, _Unsort(lb)), plan.recv_splits, plan.send_splits, group)
+        out = ops.combine(y, bins, idx, w, combine_mode, T)
+        ctx.saved = (bins, lb, plan, rs, hpre, hact, y)
+        ctx.tab, ctx.w, ctx.group, ctx.n_params = tab, w, group, len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        bins, lb, plan, rs, hpre, hact, y = ctx.saved
+        ctx.saved = None
+        tab, group = ctx.tab, ctx.group
+        assert tab.layout == L.B_NK
+        E, dev, pd = tab.E, dout.device, tab.param_dtype
+        T = dout.shape[0]
+        dy, dw = ops.combine_bwd(dout.contiguous(), y, bins, ctx.w, want_dw=ctx.needs_input_grad[1])
+        dys = ops.dispatch_rows(a2a_rows(dy, plan.send_splits, plan.recv_splits, group), lb)
+        dh = ops.grouped_gemm(dys, tab.w2_ptrs, L.B_KN, tab.F, tab.F, lb.offsets, E, epilogue=L.EPI_ACTGRAD, act=tab.act, aux=hpre)
+        pg = [None] * ctx.n_params
+        if any(ctx.needs_input_grad[7:]):
+            es = torch.tensor([], dtype=pd).element_size()
+
+            def table(buf):
+                return buf.data_ptr() + torch.arange(E, device=dev, dtype=torch.int64) * (buf[0].numel() * es)
+
+            gW2 = torch.empty(E, tab.Dout, tab.F, dtype=pd, device=dev)
+            ops.grouped_wgrad(dys, hact, lb.offsets, E, gW2, table(gW2))
+            gW1 = torch.empty(E, tab.F, tab.D, dtype=pd, device=dev)
+            ops.grouped_wgrad(dh, rs, lb.offsets, E, gW1, table(gW1))
+            seq = [gW1]
+            if tab.b1_ptrs is not None:
+                gb1 = torch.empty(E, tab.F, dtype=pd, device=dev)
+                ops.grouped_colsum(dh, lb.offsets, E, gb1, table(gb1))
+                seq.append(gb1)
+            seq.append(gW2)
+            if tab.b2_ptrs is not None:
+                gb2 = torch.empty(E, tab.Dout, dtype=pd, device=dev)
+                ops.grouped_colsum(dys, lb.offsets, E, gb2, table(gb2))
+                seq.append(gb2)
+            pg = [g[e] for g in seq for e in range(E)]
+        dx2 = None
+        if ctx.needs_input_grad[0]:
+            dxs_s = ops.grouped_gemm(dh, tab.w1_ptrs, L.B_KN, tab.D, tab.D, lb.offsets, E)
+            dxs = a2a_rows(ops.dispatch_rows(dxs_s, _Unsort(lb)), plan.recv_splits, plan.send_splits, group)
+            dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
+        return (dx2, dw, None, None, None, None, None, *pg)
+
+
+# ------------------------------------------------------------------------------------------------ module
+@register_moe("smoe_ep")
+class EPSMoeLayer(MoeLayer):
+    """`smoe` with expert-parallel experts.  `num_of_experts` is the GLOBAL expert count; `expert` is an nn.ModuleList
+    with this rank's E/P local experts (global ids rank*E/P ...).  The gate is replicated: its gradient is summed over the
+    group after backward (tokens are data-parallel); expert gradients are local by construction."""
+
+    def __init__(self, in_embed_dim=768, out_embed_dim=768, num_of_experts=4, num_selected=2, expert=None, args=None, group=None):
+        if not isinstance(expert, nn.ModuleList):
+            raise ValueError("EPSMoeLayer: pass this rank's local experts as an nn.ModuleList")
+        super().__init__(in_embed_dim, out_embed_dim, num_of_experts, num_selected, expert, args)
+        self.group = group
+        self.init_gate_weights()
+        self.gate.weight.register_post_accumulate_grad_hook(self._sync_gate_grad)
+
+    def _sync_gate_grad(self, p):
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(p.grad, group=self.group)
+
+    def forward(self, x, return_id_experts=False, is_vision=False):
+        B, N, D = x.shape
+        gate_logits = self.gate_logits(x)
+        weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
+        tab, params = self._expert_table(len(self.experts), x.dtype, x.device)
+        out = EPFFN.apply(x.reshape(B * N, D), weights.reshape(B * N, -1).contiguous(),
+                          selected_experts.reshape(B * N, -1).contiguous(), tab, self.num_of_experts, self.group,
+                          L.COMBINE_SEQ, *params)
+        output = out.view(B, N, -1)
+        auxiliary_loss = torch.tensor(0.0, device=x.device, dtype=x.dtype)
+        infor_aux = {}
+        if x.requires_grad or return_id_experts:
+            # per-rank losses on local tokens, as data-parallel training of the reference computes them
+            auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(selected_experts, gate_softmax, gate_logits)
+            infor_aux = {"balance_loss": balance_loss.clone().detach(), "router_z_loss": router_z_loss.clone().detach()}
+        return output, auxiliary_loss, None, infor_aux

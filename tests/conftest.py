@@ -8,7 +8,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _ensure_built():
+    """The C-ABI library is a build product (git-ignored): compile it once if the checkout does not have it yet."""
+    lib = os.path.join(ROOT, "competesmoe_amd", "lib", "libcsmoe_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def pytest_configure(config):
+    _ensure_built()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

@@ -1,0 +1,73 @@
+"""CPU, world_size 2, gloo: the expert-parallel exchange plumbing (plan, variable-size all-to-all, local regrouping)
+reproduces the single-process result.  The HIP kernels between the exchanges are replaced here by a stand-in per-row
+'expert' (row * (global_expert_id + 1)) -- the N>1 compute itself is covered on the GPU (tests/test_ep_gpu.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, T, D, E, K, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from competesmoe_amd import ep
+        from oracle import moe_oracle as O
+        g = torch.Generator().manual_seed(100 + rank)
+        x = torch.randn(T, D, generator=g)
+        sc = torch.rand(T, E, generator=g)
+        if rank == 0:
+            sc[:, 0] += 1.0            # skew: rank 0's tokens prefer expert 0
+        sc[:, E - 1] = -1.0            # last expert never selected (empty bin)
+        idx = sc.topk(K, -1).indices.int()
+        counts, offsets, perm = O.bin_tokens(idx, E)
+        xs = x[(perm // K)]
+        plan = ep.make_plan(counts.int(), None)
+        El = E // world
+        assert plan.send_splits == [int(counts[p * El:(p + 1) * El].sum()) for p in range(world)]
+        recv = ep.a2a_rows(xs, plan.send_splits, plan.recv_splits)
+        ids = ep.local_expert_ids(plan)
+        assert recv.shape[0] == plan.R == ids.numel()
+        # stand-in expert: scale by (global expert id + 1)
+        gid = ids.long() + rank * El
+        y_recv = recv * (gid + 1).unsqueeze(1).float()
+        y = ep.a2a_rows(y_recv, plan.recv_splits, plan.send_splits)
+        # single-process expectation in the local binned order
+        e_sorted = idx.flatten()[perm].long()
+        exp = xs * (e_sorted + 1).unsqueeze(1).float()
+        ok = torch.equal(y, exp)
+        # all ranks' counts line up: recv_counts[s] == rank s's send counts for my experts
+        allc = [torch.zeros(E, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(allc, counts.int())
+        for s in range(world):
+            ok = ok and torch.equal(plan.recv_counts[s], allc[s][rank * El:(rank + 1) * El])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T,D,E,K", [(64, 8, 8, 2), (33, 4, 4, 1), (128, 16, 16, 3)])
+def test_ep_exchange_two_ranks_gloo(T, D, E, K):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, T, D, E, K, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res == {0: True, 1: True}

@@ -1,0 +1,118 @@
+"""GPU: the expert-parallel layer gives the single-GPU layer's numbers.
+
+(1) world_size 1 over RCCL ("nccl") on the one GPU of the box: EPSMoeLayer == SMoeLayer bit for bit.
+(2) world_size 2, both ranks on cuda:0 (RCCL refuses two ranks on one device, so for THIS test only the two collectives
+    are carried by gloo through host memory): each rank's EP output equals the full single-GPU layer on its tokens, and the
+    local expert gradients equal the sum over ranks of the single-GPU gradients."""
+import os
+import socket
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _experts(E, D, F, seed, dt, dev):
+    torch.manual_seed(seed)
+    ex = nn.ModuleList([nn.Sequential(nn.Linear(D, F), nn.GELU(), nn.Linear(F, D)) for _ in range(E)])
+    return ex.to(dev).to(dt)
+
+
+def _run(rank, world, port, backend, dt_name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from competesmoe_amd import ep
+        from competesmoe_amd.moe import get_moe
+        if backend == "gloo":
+            real = dist.all_to_all_single
+
+            def via_host(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+                o = torch.empty(out.shape, dtype=out.dtype)
+                real(o, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+                out.copy_(o)
+            dist.all_to_all_single = via_host
+        dt = torch.float32 if dt_name == "fp32" else torch.bfloat16
+        B, N, D, F, E, K = 2, 96, 64, 128, 8, 2
+        args = types.SimpleNamespace(balance_loss_coef=0.01, router_z_loss_coef=0.001)
+        full = get_moe("smoe")(D, D, E, K, _experts(E, D, F, 7, dt, dev), args).to(dev).to(dt).train()
+        El = E // world
+        local = nn.ModuleList([_experts(E, D, F, 7, dt, dev)[rank * El + i] for i in range(El)])
+        epl = ep.EPSMoeLayer(D, D, E, K, local, args).to(dev).to(dt).train()
+        g = torch.Generator().manual_seed(50 + rank)
+        x = torch.randn(B, N, D, generator=g).to(dt).to(dev)
+        dy = torch.randn(B, N, D, generator=g).to(dt).to(dev)
+        xa = x.clone().requires_grad_(True)
+        xb = x.clone().requires_grad_(True)
+        oa, aa, _, _ = full(xa)
+        torch.autograd.backward([oa, aa.float()], [dy, torch.ones((), device=dev)])
+        ob, ab, _, _ = epl(xb)
+        torch.autograd.backward([ob, ab.float()], [dy, torch.ones((), device=dev)])
+        torch.cuda.synchronize()
+        ok = torch.equal(oa, ob) and float(aa) == float(ab)
+        ok = ok and torch.equal(xa.grad, xb.grad)
+        # expert grads: EP local grads == sum over ranks of the single-GPU grads for those experts
+        tol = 1e-5 if dt == torch.float32 else 2e-2
+        for i in range(El):
+            for (n1, p1), (n2, p2) in zip(full.experts[rank * El + i].named_parameters(), epl.experts[i].named_parameters()):
+                pass
+        refs = []
+        for e in range(E):
+            for p in full.experts[e].parameters():
+                gsum = p.grad.detach().float().cpu()
+                if world > 1:
+                    dist.all_reduce(gsum)     # gloo, host tensors
+                refs.append(gsum)
+        mine = [p.grad.detach().float().cpu() for i in range(El) for p in epl.experts[i].parameters()]
+        per = len(list(full.experts[0].parameters()))
+        for j, gm in enumerate(mine):
+            gr = refs[rank * El * per + j]
+            err = float((gm - gr).norm() / (gr.norm() + 1e-12))
+            ok = ok and err <= tol
+        # replicated gate: EP grad is the all-reduced sum
+        gg = full.gate.weight.grad.detach().float().cpu()
+        if world > 1:
+            dist.all_reduce(gg)
+        ok = ok and float((epl.gate.weight.grad.float().cpu() - gg).norm() / gg.norm()) <= tol
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _launch(world, backend, dt_name):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, backend, dt_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    return dict(q.get(timeout=5) for _ in range(world))
+
+
+@pytest.mark.parametrize("dt_name", ["fp32", "bf16"])
+def test_ep_world1_rccl_equals_single_gpu(dt_name):
+    assert _launch(1, "nccl", dt_name) == {0: True}
+
+
+@pytest.mark.parametrize("dt_name", ["fp32", "bf16"])
+def test_ep_world2_one_gpu_equals_single_gpu(dt_name):
+    assert _launch(2, "gloo", dt_name) == {0: True, 1: True}
