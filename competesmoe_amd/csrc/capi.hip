@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 // ---- kernels implemented in the other translation units
 int gg_generic_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
@@ -20,6 +21,12 @@ int gg_fast_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int 
 bool gg_fast_wgrad_ok(int64_t lda, int64_t ldb, int64_t ldc, int M, int Na, int Nb, const void* A, const void* B);
 int gg_fast_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
                   void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st);
+int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                 const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                 const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
+                 hipStream_t st);
+int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
+              void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st);
 int k_router_select(const void*, int, int, int, int, int, int, float*, int32_t*, float*, hipStream_t);
 int k_router_select_bwd(const void*, int, int, int, int, int, int, const float*, const int32_t*, const float*, const float*,
                         const float*, void*, hipStream_t);
@@ -40,6 +47,29 @@ void csmoe_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// Kernel choice for the bf16 grouped GEMMs: v2 (256x256 tile, pipelined LDS-DMA) for big problems, v1 (128x128) for
+// small / narrow ones.  CSMOE_GEMM_KERNEL=v1|v2 forces one (A/B runs); read once.
+static int gemm_pref() {
+  static int pref = -1;
+  if (pref < 0) {
+    const char* e = getenv("CSMOE_GEMM_KERNEL");
+    pref = (e && !strcmp(e, "v1")) ? 1 : (e && !strcmp(e, "v2")) ? 2 : 0;
+  }
+  return pref;
+}
+static bool use_v2_rowspace(int M, int N, int Kd) {
+  int p = gemm_pref();
+  if (p == 1) return false;
+  if (p == 2) return true;
+  return N >= 256 && Kd >= 128 && M >= 2048;
+}
+static bool use_v2_wgrad(int M, int Na, int Nb) {
+  int p = gemm_pref();
+  if (p == 1) return false;
+  if (p == 2) return true;
+  return Na >= 256 && Nb >= 256 && M >= 512;
 }
 
 static inline bool dtype_ok(int d) { return d == CSMOE_F32 || d == CSMOE_BF16; }
@@ -154,9 +184,13 @@ int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, in
   CSMOE_CHECK_ARG(lda >= Kd && ldc >= N && ldb >= (b_layout == CSMOE_B_NK ? Kd : N), "grouped_gemm: leading dimension too small");
   if (M == 0) return CSMOE_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C))
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C)) {
+    if (use_v2_rowspace(M, N, Kd))
+      return gg8_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
+                          nullptr, nullptr, st);
     return gg_fast_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
                             nullptr, nullptr, st);
+  }
   return gg_generic_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
                              dtype, nullptr, nullptr, st);
 }
@@ -169,9 +203,13 @@ int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, in
   CSMOE_CHECK_ARG(epilogue != CSMOE_EPI_ACTGRAD || aux, "dense_gemm: ACTGRAD epilogue needs aux");
   if (M == 0) return CSMOE_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C))
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C)) {
+    if (use_v2_rowspace(M, N, Kd))
+      return gg8_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B,
+                          bias, st);
     return gg_fast_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B,
                             bias, st);
+  }
   return gg_generic_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act,
                              dtype, B, bias, st);
 }
@@ -185,8 +223,11 @@ int csmoe_grouped_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, 
   CSMOE_CHECK_ARG(lda >= Na && ldb >= Nb && ldc >= Nb, "grouped_wgrad: leading dimension too small");
   CSMOE_CHECK_ARG(!(dtype == CSMOE_F32 && out_dtype != CSMOE_F32), "grouped_wgrad: fp32 inputs need fp32 output");
   hipStream_t st = (hipStream_t)stream;
-  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_wgrad_ok(lda, ldb, ldc, M, Na, Nb, A, B))
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_wgrad_ok(lda, ldb, ldc, M, Na, Nb, A, B)) {
+    if (use_v2_wgrad(M, Na, Nb))
+      return gg8_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, out_dtype, accumulate, 0, nullptr, st);
     return gg_fast_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, out_dtype, accumulate, 0, nullptr, st);
+  }
   return gg_generic_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, dtype, out_dtype, accumulate, 0, nullptr, st);
 }
 
@@ -196,8 +237,11 @@ int csmoe_dense_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, in
   CSMOE_CHECK_ARG(C && (M == 0 || (A && B)), "dense_wgrad: null pointer");
   CSMOE_CHECK_ARG(!(dtype == CSMOE_F32 && out_dtype != CSMOE_F32), "dense_wgrad: fp32 inputs need fp32 output");
   hipStream_t st = (hipStream_t)stream;
-  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_wgrad_ok(lda, ldb, ldc, M, Na, Nb, A, B))
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_wgrad_ok(lda, ldb, ldc, M, Na, Nb, A, B)) {
+    if (use_v2_wgrad(M, Na, Nb))
+      return gg8_wgrad(A, lda, B, ldb, nullptr, 1, Na, Nb, nullptr, ldc, out_dtype, accumulate, M, C, st);
     return gg_fast_wgrad(A, lda, B, ldb, nullptr, 1, Na, Nb, nullptr, ldc, out_dtype, accumulate, M, C, st);
+  }
   return gg_generic_wgrad(A, lda, B, ldb, nullptr, 1, Na, Nb, nullptr, ldc, dtype, out_dtype, accumulate, M, C, st);
 }
 

@@ -18,147 +18,17 @@
 //
 // Replaces: cvmm_kernel / cvmm_backward_kernel3 (moe_pretrain_model/layers/cvmm.py:61-168, 194-345) and the per-expert
 // nn.Linear loop of compute_moe (moe_model/model/moe/moe.py:196-204).
-#include "common.h"
+#include "gemm_tiles.h"
 #include <algorithm>
+
+using namespace ggt;
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_B = 16384;               // one operand tile in LDS
 constexpr int STAGE_B = 2 * TILE_B;
-constexpr unsigned OOB = 0x80000000u;       // any offset >= num_records reads as zero
 constexpr int CT_LD = BN + 4;               // fp32 epilogue tile row stride (floats)
 constexpr int LDS_BYTES = BM * CT_LD * 4;   // 67,584 B >= the two K-loop stages (65,536 B)
-
-enum { KC = 0, KM = 1 };
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-struct FastArgs {
-  // row operand ("tokens" / wgrad A): [*, ld_r]; col operand (weights / wgrad B)
-  const void* R; int64_t ld_r;
-  const void* Cflat; int64_t ld_c;            // wgrad col operand (flat [M, Nb])
-  const void* const* c_ptrs_in;               // row-space: per-expert weight pointers
-  const void* const* bias_ptrs;
-  const int32_t* offsets; int E;
-  int single_M; const void* single_B; const void* single_bias; void* single_C;
-  int NR;      // row-space: unused;  wgrad: Na (output rows)
-  int NC;      // output columns (N or Nb)
-  int Kd;      // row-space reduction length
-  void* C; void* C2; const void* aux; int64_t ldc;
-  void* const* out_ptrs;                      // wgrad outputs
-  int epilogue, act, accumulate, out_f32;
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
-
-// ---- DMA issue: one 16 KiB operand tile = 4 wave-instructions per wave --------------------------------------------
-// KC: tile rows are operand rows (stride ld_bytes), 64 reduction elements per row starting at red0.
-template <int KIND>
-__device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const unsigned (&vbase)[4],
-                                         const int (&aux)[4], int red0, int red_len, unsigned ld_bytes, int wave) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned voff;
-    if (KIND == KC) {
-      // aux[j] = first reduction element of this lane's chunk within the K-tile
-      voff = vbase[j] + (unsigned)red0 * 2u;
-      if (red0 + aux[j] >= red_len) voff = OOB;
-    } else {
-      // vbase[j] already OOB for out-of-range columns; reduction rows past the end fall off num_records
-      voff = vbase[j] + (unsigned)red0 * ld_bytes;
-    }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + (wave * 4 + j) * 1024), 16, voff, 0, 0, 0);
-  }
-}
-
-// per-lane, loop-invariant DMA source offsets
-template <int KIND>
-__device__ __forceinline__ void dma_setup(unsigned (&vbase)[4], int (&aux)[4], unsigned ld_bytes, int col0, int ncols,
-                                          int wave, int lane) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int P = (wave * 4 + j) * 64 + lane;
-    if (KIND == KC) {
-      int r = P >> 3, pc = P & 7;
-      int c = pc ^ ((r >> 1) & 7);
-      vbase[j] = (unsigned)r * ld_bytes + (unsigned)c * 16u;
-      aux[j] = c * 8;
-    } else {
-      int k = P >> 4, pc = P & 15;
-      int f = (k & 3) | (((k >> 3) & 1) << 2);
-      int seg = (pc >> 1) ^ f;
-      int col = col0 + seg * 16 + (pc & 1) * 8;
-      vbase[j] = (col < ncols) ? ((unsigned)k * ld_bytes + (unsigned)col * 2u) : OOB;
-      aux[j] = 0;
-    }
-  }
-}
-
-// ---- fragment reads ------------------------------------------------------------------------------------------------
-// KC: block b = 16 operand rows; returns the 8 reduction elements k = s*32 + 8*(lane>>4) .. +7 of row (lane&15)
-__device__ __forceinline__ bf16x8 frag_kc(const char* tile, int lane_off, int b, int s) {
-  return *(const bf16x8*)(tile + b * 2048 + (lane_off ^ (s << 6)));
-}
-// KM: column block cb; two transposed 4x16 reads
-__device__ __forceinline__ bf16x8 frag_km(const char* tile, int addr_cb, int s) {
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + addr_cb + s * 8192));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + addr_cb + s * 8192 + 1024));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-// activation over 8 values, `switch` outside the element loop so each formula is emitted once
-__device__ __forceinline__ void act_fwd8(float (&v)[8], int act) {
-  switch (act) {
-    case CSMOE_ACT_RELU:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_RELU);
-      break;
-    case CSMOE_ACT_GELU:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_GELU);
-      break;
-    case CSMOE_ACT_GELU_TANH:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_GELU_TANH);
-      break;
-    case CSMOE_ACT_SILU:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_SILU);
-      break;
-    default: break;
-  }
-}
-// h[j] <- act'(h[j])
-__device__ __forceinline__ void act_bwd8(float (&h)[8], int act) {
-  switch (act) {
-    case CSMOE_ACT_RELU:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_RELU);
-      break;
-    case CSMOE_ACT_GELU:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_GELU);
-      break;
-    case CSMOE_ACT_GELU_TANH:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_GELU_TANH);
-      break;
-    case CSMOE_ACT_SILU:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_SILU);
-      break;
-    default:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = 1.f;
-      break;
-  }
-}
 
 template <int ROWK, int COLK, int MODE>
 __global__ void __launch_bounds__(256, 2) gg_fast_kernel(FastArgs p) {
@@ -215,21 +85,21 @@ __global__ void __launch_bounds__(256, 2) gg_fast_kernel(FastArgs p) {
   if (MODE == 0) {
     // rows of this expert's m-tile, [rows, Kd]
     rs_r = make_rsrc((const char*)p.R + (int64_t)row0 * ldr_b, (unsigned)rows * ldr_b);
-    dma_setup<KC>(vb_r, ax_r, ldr_b, 0, 0, wave, lane);
+    dma_setup<KC, 4>(vb_r, ax_r, ldr_b, 0, 0, 7, 0, 0, wave, lane);
     const char* wb = (const char*)(p.c_ptrs_in ? p.c_ptrs_in[e] : p.single_B);
     if (COLK == KC) {   // weight [N, Kd]: tile rows = n
       int nrows = min(BN, p.NC - tc0);
       rs_c = make_rsrc(wb + (int64_t)tc0 * ldc_b, (unsigned)nrows * ldc_b);
-      dma_setup<KC>(vb_c, ax_c, ldc_b, 0, 0, wave, lane);
+      dma_setup<KC, 4>(vb_c, ax_c, ldc_b, 0, 0, 7, 0, 0, wave, lane);
     } else {            // weight [Kd, N]: tile rows = k, cols = n
       rs_c = make_rsrc(wb, (unsigned)p.Kd * ldc_b);
-      dma_setup<KM>(vb_c, ax_c, ldc_b, tc0, p.NC, wave, lane);
+      dma_setup<KM, 4>(vb_c, ax_c, ldc_b, tc0, p.NC, 7, 0, 0, wave, lane);
     }
   } else {
     rs_r = make_rsrc((const char*)p.R + (int64_t)row0 * ldr_b, (unsigned)red_len * ldr_b);
-    dma_setup<KM>(vb_r, ax_r, ldr_b, tr0, p.NR, wave, lane);
+    dma_setup<KM, 4>(vb_r, ax_r, ldr_b, tr0, p.NR, 7, 0, 0, wave, lane);
     rs_c = make_rsrc((const char*)p.Cflat + (int64_t)row0 * ldc_b, (unsigned)red_len * ldc_b);
-    dma_setup<KM>(vb_c, ax_c, ldc_b, tc0, p.NC, wave, lane);
+    dma_setup<KM, 4>(vb_c, ax_c, ldc_b, tc0, p.NC, 7, 0, 0, wave, lane);
   }
 
   // ---------------- LDS read addressing ----------------
@@ -254,8 +124,8 @@ __global__ void __launch_bounds__(256, 2) gg_fast_kernel(FastArgs p) {
 
   const int nk = (red_len + BK - 1) / BK;
   if (nk > 0) {
-    dma_tile<ROWK>(rs_r, smem, vb_r, ax_r, 0, red_len, ldr_b, wave);
-    dma_tile<COLK>(rs_c, smem + TILE_B, vb_c, ax_c, 0, red_len, ldc_b, wave);
+    dma_tile<ROWK, 4>(rs_r, smem, vb_r, ax_r, 0, red_len, ldr_b, wave);
+    dma_tile<COLK, 4>(rs_c, smem + TILE_B, vb_c, ax_c, 0, red_len, ldc_b, wave);
   }
   __syncthreads();
 
@@ -263,8 +133,8 @@ __global__ void __launch_bounds__(256, 2) gg_fast_kernel(FastArgs p) {
     char* cur = smem + (kt & 1) * STAGE_B;
     char* nxt = smem + ((kt + 1) & 1) * STAGE_B;
     if (kt + 1 < nk) {
-      dma_tile<ROWK>(rs_r, nxt, vb_r, ax_r, (kt + 1) * BK, red_len, ldr_b, wave);
-      dma_tile<COLK>(rs_c, nxt + TILE_B, vb_c, ax_c, (kt + 1) * BK, red_len, ldc_b, wave);
+      dma_tile<ROWK, 4>(rs_r, nxt, vb_r, ax_r, (kt + 1) * BK, red_len, ldr_b, wave);
+      dma_tile<COLK, 4>(rs_c, nxt + TILE_B, vb_c, ax_c, (kt + 1) * BK, red_len, ldc_b, wave);
     }
     const char* tr = cur;
     const char* tc = cur + TILE_B;

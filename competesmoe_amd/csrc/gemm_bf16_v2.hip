@@ -1,0 +1,386 @@
+// Grouped expert GEMM v2 for gfx950: 256x256 output tile, 512 threads (8 waves as 2 row-halves x 4 column-quarters, each
+// wave 128x64 = 8x4 v_mfma_f32_16x16x32_bf16 accumulators), K-tile 64, 128 KiB of LDS, one workgroup per CU.
+//
+// LDS holds 4 kinds of 16 KiB images (the KC / KM images of gemm_tiles.h), two slots each (K-tile parity):
+//     RL = rows  0..63  of both row halves      (what every wave reads in phase 1)      CL = columns  0..31 of the 4 quarters
+//     RH = rows 64..127 of both row halves      (phase 3)                               CH = columns 32..63 of the 4 quarters
+// Every K-tile s is 4 phases; a phase = {fragment ds_reads, issue ONE image by LDS-DMA (2 x 1 KiB per wave), counted vmcnt,
+// lgkmcnt(0), s_barrier A, 16 MFMA (a 64x32 quadrant of the wave tile over K=64), s_barrier B}; wave (wm, wn) owns rows
+// wm*64+0..63 of BOTH row images and columns wn*32+0..31 of BOTH column images, so each image is consumed in exactly one phase:
+//     phase 1: read CL,RL(s)   MFMA C_lo x R_lo        phase 3: read RH(s)    MFMA C_hi x R_hi
+//     phase 2: read CH(s)      MFMA C_hi x R_lo        phase 4: (C_lo kept)   MFMA C_lo x R_hi
+// Two DMA schedules (template SCHED), both re-filling a slot only after the phase that read it and waiting with a COUNTED
+// vmcnt so the loop never drains the DMA queue (guide §5 "Pipelining across barriers"):
+//     SHALLOW: P1 RL(s+1)  P2 RH(s+1)  P3 CL(s+2)  P4 CH(s+2), vmcnt(4) in P4      (2-4 images in flight)
+//     DEEP   : P1 RH(s+1)  P2 RL(s+2)  P3 CL(s+2)  P4 CH(s+2), vmcnt(10) in P1,P2,P4 (5-6 images = 80-96 KiB in flight)
+// Measured (profiles/r01): DEEP is best for the K-contiguous (nn.Linear) layout, SHALLOW for K-major images.
+// Row half 1 (waves 4-7, the SIMD partners of waves 0-3) runs half a phase behind: one hardware barrier is A for one group and
+// B for the other, so one group's ds_reads / DMA issue overlap its partners' MFMAs ("Two waves per SIMD" item 9 of the
+// microarch guide; +9 % here).  Safety under the stagger: reads are retired (lgkmcnt(0)) and the counted vmcnt is taken BEFORE
+// barrier A, so whichever group is ahead can neither re-fill a slot the other still reads nor read an image the other has not
+// finished fetching.  K-tiles past the end are still "issued": their offsets are out of range, the buffer descriptor turns
+// them into zero-fills of slots nobody reads, which keeps the wait counts uniform.
+// In-kernel s_memtime stamps of this loop (diagnostic build, profiles/r01/gemm_v2_stamps.txt): per phase ~450 cycles of
+// read/issue/wait, ~380 of MFMA and ~170 of release latency per barrier -- an LDS-DMA issue costs its wave 100-185 cycles.
+#include "gemm_tiles.h"
+#include <algorithm>
+#include <cstdlib>
+
+using namespace ggt;
+
+namespace {
+
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
+constexpr int BUF_B = 4 * TILE_B;            // one K-tile buffer: R0, R1, C0, C1
+constexpr int CT2_LD = BN2 + 4;              // fp32 epilogue staging row stride (floats); 128 rows per pass
+constexpr int LDS2_BYTES = 128 * CT2_LD * 4; // 133,120 B  (>= 2 * BUF_B = 131,072 B)
+
+enum { SHALLOW = 0, DEEP = 1 };
+
+template <int ROWK, int COLK, int MODE, int SCHED>
+__global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;       // row half, column quarter
+
+  // ---------------- tile lookup ----------------
+  int e, row0 = 0, rows = 0, tr0 = 0, tc0 = 0, red_len;
+  const int nct = (p.NC + BN2 - 1) / BN2;
+  if (MODE == 0) {
+    int total = 0;
+    for (int i = 0; i < p.E; ++i) total += ((p.offsets ? p.offsets[i + 1] - p.offsets[i] : p.single_M) + BM2 - 1) / BM2;
+    total *= nct;
+    if ((int)blockIdx.x >= total) return;
+    int v = xcd_remap(blockIdx.x, total);
+    int accb = 0, mt_e = 0, o0 = 0, o1 = 0;
+    e = 0;
+    for (int i = 0; i < p.E; ++i) {
+      o0 = p.offsets ? p.offsets[i] : 0; o1 = p.offsets ? p.offsets[i + 1] : p.single_M;
+      mt_e = (o1 - o0 + BM2 - 1) / BM2;
+      if (v < accb + mt_e * nct) { e = i; break; }
+      accb += mt_e * nct;
+    }
+    int local = v - accb;
+    int mt = local % mt_e, nt = local / mt_e;
+    row0 = o0 + mt * BM2; rows = min(BM2, o1 - row0);
+    tc0 = nt * BN2;
+    red_len = p.Kd;
+  } else {
+    const int nrt = (p.NR + BM2 - 1) / BM2;
+    const int per_e = nrt * nct;
+    int v = xcd_remap(blockIdx.x, per_e * p.E);
+    e = v / per_e;
+    int local = v - e * per_e;
+    tr0 = (local / nct) * BM2; tc0 = (local % nct) * BN2;
+    row0 = p.offsets ? p.offsets[e] : 0;
+    red_len = (p.offsets ? p.offsets[e + 1] : p.single_M) - row0;
+  }
+  e = __builtin_amdgcn_readfirstlane(e);
+  row0 = __builtin_amdgcn_readfirstlane(row0);
+  rows = __builtin_amdgcn_readfirstlane(rows);
+  tr0 = __builtin_amdgcn_readfirstlane(tr0);
+  tc0 = __builtin_amdgcn_readfirstlane(tc0);
+  red_len = __builtin_amdgcn_readfirstlane(red_len);
+
+  // ---------------- operand descriptors + per-lane DMA offsets of the 4 image kinds ----------------
+  const unsigned ldr_b = (unsigned)p.ld_r * 2u, ldc_b = (unsigned)p.ld_c * 2u;
+  __amdgpu_buffer_rsrc_t rs_r, rs_c;
+  unsigned vb_rl[2], vb_rh[2], vb_cl[2], vb_ch[2];
+  int ax_r[2], ax_c[2], ax_dummy[2];
+  // RL / RH = tile rows [0,128) / [128,256); CL / CH = tile columns [0,128) / [128,256): contiguous, fully coalesced images.
+  // Wave (wm, wn) owns rows {wm*64 + 0..63} of BOTH row images and columns {wn*32 + 0..31} of BOTH column images, i.e. four
+  // 64x32 blocks of the 256x256 tile, so every image is consumed in exactly one phase by all eight waves.
+  if (MODE == 0) {
+    rs_r = make_rsrc((const char*)p.R + (int64_t)row0 * ldr_b, (unsigned)rows * ldr_b);
+    dma_setup<KC, 2>(vb_rl, ax_r, ldr_b, 0, 0, 7, 0, 0, wave, lane);
+    dma_setup<KC, 2>(vb_rh, ax_dummy, ldr_b, 0, 0, 7, 0, 128, wave, lane);
+    const char* wb = (const char*)(p.c_ptrs_in ? p.c_ptrs_in[e] : p.single_B);
+    if (COLK == KC) {
+      int nrows = min(BN2, p.NC - tc0);
+      rs_c = make_rsrc(wb + (int64_t)tc0 * ldc_b, (unsigned)nrows * ldc_b);
+      dma_setup<KC, 2>(vb_cl, ax_c, ldc_b, 0, 0, 7, 0, 0, wave, lane);
+      dma_setup<KC, 2>(vb_ch, ax_dummy, ldc_b, 0, 0, 7, 0, 128, wave, lane);
+    } else {
+      rs_c = make_rsrc(wb, (unsigned)p.Kd * ldc_b);
+      dma_setup<KM, 2>(vb_cl, ax_c, ldc_b, tc0, p.NC, 7, 0, 0, wave, lane);
+      dma_setup<KM, 2>(vb_ch, ax_dummy, ldc_b, tc0, p.NC, 7, 0, 128, wave, lane);
+    }
+  } else {
+    rs_r = make_rsrc((const char*)p.R + (int64_t)row0 * ldr_b, (unsigned)red_len * ldr_b);
+    dma_setup<KM, 2>(vb_rl, ax_r, ldr_b, tr0, p.NR, 7, 0, 0, wave, lane);
+    dma_setup<KM, 2>(vb_rh, ax_dummy, ldr_b, tr0, p.NR, 7, 0, 128, wave, lane);
+    rs_c = make_rsrc((const char*)p.Cflat + (int64_t)row0 * ldc_b, (unsigned)red_len * ldc_b);
+    dma_setup<KM, 2>(vb_cl, ax_c, ldc_b, tc0, p.NC, 7, 0, 0, wave, lane);
+    dma_setup<KM, 2>(vb_ch, ax_dummy, ldc_b, tc0, p.NC, 7, 0, 128, wave, lane);
+  }
+
+  // ---------------- LDS read addressing ----------------
+  const int g = lane >> 4, i16 = lane & 15;
+  const int kc_lane = i16 * 128 + ((g ^ (i16 >> 1)) << 4);
+  const int q = i16 >> 2, pp = i16 & 3;
+  const int fk = q | ((g & 1) << 2);
+  // this wave's 16-row / 16-column blocks inside an image: R images blocks wm*4 + 0..3, C images blocks wn*2 + 0..1
+  const int r_blk0 = wm * 4, c_blk0 = wn * 2;
+  int km_r[4], km_c[2];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) km_r[b] = (8 * g + q) * 256 + (((r_blk0 + b) ^ fk) << 5) + pp * 8;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) km_c[b] = (8 * g + q) * 256 + (((c_blk0 + b) ^ fk) << 5) + pp * 8;
+
+  f32x4 acc[4][8];   // [column block][row block]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (red_len + BK2 - 1) / BK2;
+
+  // slot(kind, parity) = (parity * 4 + kind) * 16 KiB with kind RL=0, CL=1, CH=2, RH=3
+#define SLOT(kind, tile) (smem + ((((tile) & 1) * 4 + (kind)) * TILE_B))
+#define ISSUE_RL(tile) dma_tile<ROWK, 2>(rs_r, SLOT(0, tile), vb_rl, ax_r, (tile) * BK2, red_len, ldr_b, wave)
+#define ISSUE_CL(tile) dma_tile<COLK, 2>(rs_c, SLOT(1, tile), vb_cl, ax_c, (tile) * BK2, red_len, ldc_b, wave)
+#define ISSUE_CH(tile) dma_tile<COLK, 2>(rs_c, SLOT(2, tile), vb_ch, ax_c, (tile) * BK2, red_len, ldc_b, wave)
+#define ISSUE_RH(tile) dma_tile<ROWK, 2>(rs_r, SLOT(3, tile), vb_rh, ax_r, (tile) * BK2, red_len, ldr_b, wave)
+#define WAIT_DMA(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+  // barrier A closes a phase's read/issue section (reads retired, counted DMA wait taken), barrier B its MFMA section
+#define PHASE_SYNC_IN()                                \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+  __builtin_amdgcn_s_barrier();                        \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  __builtin_amdgcn_s_setprio(1)
+#define PHASE_SYNC_OUT()                               \
+  __builtin_amdgcn_s_setprio(0);                       \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  __builtin_amdgcn_s_barrier();                        \
+  __builtin_amdgcn_sched_barrier(0)
+#define MFMA_QUADRANT(FC, FR, CB0, RB0)                                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                   \
+    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                                 \
+      _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                               \
+        acc[(CB0) + cb][(RB0) + rb] =                                                                                \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FC[cb][ks], FR[rb][ks], acc[(CB0) + cb][(RB0) + rb], 0, 0, 0)
+
+  // ragged tiles: a wave whose 64-row / 32-column strips lie outside the tile skips those reads and MFMAs (it still issues
+  // its share of the DMA and takes every barrier)
+  const int rows_here = (MODE == 0 ? rows : min(BM2, p.NR - tr0)) - wm * 64;
+  const int cols_here = min(BN2, p.NC - tc0) - wn * 32;
+  const bool act1 = rows_here > 0 && cols_here > 0;        // C_lo x R_lo
+  const bool act2 = rows_here > 0 && cols_here > 128;      // C_hi x R_lo
+  const bool act3 = rows_here > 128 && cols_here > 128;    // C_hi x R_hi
+  const bool act4 = rows_here > 128 && cols_here > 0;      // C_lo x R_hi
+
+  // prologue: K-tile 0 complete; SHALLOW also the column images of K-tile 1, DEEP all of K-tile 1 except RH
+  ISSUE_RL(0); ISSUE_CL(0); ISSUE_CH(0); ISSUE_RH(0);
+  if (SCHED == DEEP) { ISSUE_RL(1); ISSUE_CL(1); ISSUE_CH(1); WAIT_DMA(10); }
+  else               { ISSUE_CL(1); ISSUE_CH(1); WAIT_DMA(4); }
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int s = 0; s < nk; ++s) {
+    const char* base = smem + (s & 1) * (4 * TILE_B);
+    const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
+    bf16x8 fcl[2][2], fch[2][2], fr[4][2];
+
+    // ---- phase 1: C_lo x R_lo
+    if (act1 || act4) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fcl[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km(i_cl, km_c[cb], ks);
+    }
+    if (act1 || act2) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km(i_rl, km_r[rb], ks);
+    }
+    if (SCHED == DEEP) { ISSUE_RH(s + 1); WAIT_DMA(10); }   // CH(s) landed
+    else               { ISSUE_RL(s + 1); }
+    PHASE_SYNC_IN();
+    if (act1) { MFMA_QUADRANT(fcl, fr, 0, 0); }
+    PHASE_SYNC_OUT();
+
+    // ---- phase 2: C_hi x R_lo
+    if (act2 || act3) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fch[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km(i_ch, km_c[cb], ks);
+    }
+    if (SCHED == DEEP) { ISSUE_RL(s + 2); WAIT_DMA(10); }   // RH(s) landed
+    else               { ISSUE_RH(s + 1); }
+    PHASE_SYNC_IN();
+    if (act2) { MFMA_QUADRANT(fch, fr, 2, 0); }
+    PHASE_SYNC_OUT();
+
+    // ---- phase 3: C_hi x R_hi
+    if (act3 || act4) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km(i_rh, km_r[rb], ks);
+    }
+    ISSUE_CL(s + 2);
+    PHASE_SYNC_IN();
+    if (act3) { MFMA_QUADRANT(fch, fr, 2, 4); }
+    PHASE_SYNC_OUT();
+
+    // ---- phase 4: C_lo x R_hi.  After this phase's wait + barrier A every image of K-tile s+1 that phase 1 reads has landed.
+    ISSUE_CH(s + 2);
+    if (SCHED == DEEP) { WAIT_DMA(10); } else { WAIT_DMA(4); }
+    PHASE_SYNC_IN();
+    if (act4) { MFMA_QUADRANT(fcl, fr, 0, 4); }
+    PHASE_SYNC_OUT();
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
+
+  // the zero-fill DMAs of the K-tiles past the end may still be writing LDS: drain before the staging tile reuses it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---------------- epilogue: two passes of 128 rows through an fp32 LDS tile ----------------
+  float* stg = (float*)smem;
+  const int ec = (threadIdx.x & 31) * 8;       // this thread's 8 columns inside the 256-wide tile
+  const int er = threadIdx.x >> 5;             // 0..15
+  const int ncol = tc0 + ec;
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (MODE == 0 && ncol < p.NC && (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT)) {
+    const bf16* bias = (const bf16*)(p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias);
+    if (bias) {
+      bf16x8 b8 = *(const bf16x8*)(bias + ncol);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = (float)b8[j];
+    }
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    {
+      // acc[cb][rb]: rb < 4 -> row image RL, rb >= 4 -> RH; cb < 2 -> column image CL, cb >= 2 -> CH
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const int m = wm * 64 + rb * 16 + i16;
+          const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
+          *(f32x4*)(stg + m * CT2_LD + n) = pass == 0 ? acc[cb][rb] : acc[cb][4 + rb];
+        }
+    }
+    __syncthreads();
+    if (ncol < p.NC) {
+      if (MODE == 0) {
+        const int rlim = min(128, rows - pass * 128);
+#pragma unroll 1
+        for (int r = er; r < rlim; r += 16) {
+          const f32x4 lo = *(const f32x4*)(stg + r * CT2_LD + ec), hi = *(const f32x4*)(stg + r * CT2_LD + ec + 4);
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const int64_t o = (int64_t)(row0 + pass * 128 + r) * p.ldc + ncol;
+          bf16x8 o0;
+          if (p.epilogue == CSMOE_EPI_ACTGRAD) {
+            const bf16x8 h8 = *(const bf16x8*)((const bf16*)p.aux + o);
+            float h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { h[j] = (float)h8[j]; v[j] = (float)(bf16)v[j]; }
+            act_bwd8(h, p.act);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o0[j] = (bf16)(v[j] * h[j]);
+            *(bf16x8*)((bf16*)p.C + o) = o0;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o0[j] = (bf16)(v[j] + bv[j]); v[j] = (float)o0[j]; }
+            *(bf16x8*)((bf16*)p.C + o) = o0;
+            if (p.epilogue == CSMOE_EPI_BIAS_ACT && p.C2) {
+              act_fwd8(v, p.act);
+              bf16x8 o1;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o1[j] = (bf16)v[j];
+              *(bf16x8*)((bf16*)p.C2 + o) = o1;
+            }
+          }
+        }
+      } else {
+        char* Ce = (char*)(p.out_ptrs ? p.out_ptrs[e] : p.single_C);
+        const int rlim = min(128, p.NR - tr0 - pass * 128);
+#pragma unroll 1
+        for (int r = er; r < rlim; r += 16) {
+          f32x4 lo = *(const f32x4*)(stg + r * CT2_LD + ec), hi = *(const f32x4*)(stg + r * CT2_LD + ec + 4);
+          const int64_t o = (int64_t)(tr0 + pass * 128 + r) * p.ldc + ncol;
+          if (p.out_f32) {
+            f32x4* dst = (f32x4*)(Ce + o * 4);
+            if (p.accumulate) { lo += dst[0]; hi += dst[1]; }
+            dst[0] = lo; dst[1] = hi;
+          } else {
+            bf16x8* dst = (bf16x8*)(Ce + o * 2);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (p.accumulate) {
+              const bf16x8 old = *dst;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] += (float)old[j];
+            }
+            bf16x8 o8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o8[j] = (bf16)v[j];
+            *dst = o8;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename K>
+int set_lds2(K kern) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
+    if (e != hipSuccess) { csmoe_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return CSMOE_ERR_LAUNCH; }
+    done = true;
+  }
+  return CSMOE_OK;
+}
+
+}  // namespace
+
+int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                 const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                 const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
+                 hipStream_t st) {
+  FastArgs p{};
+  p.single_M = M; p.single_B = single_B; p.single_bias = single_bias;
+  p.R = A; p.ld_r = lda; p.c_ptrs_in = b_ptrs; p.ld_c = ldb; p.bias_ptrs = bias_ptrs; p.offsets = offsets; p.E = E;
+  p.NC = N; p.Kd = Kd; p.C = C; p.C2 = C2; p.aux = aux; p.ldc = ldc; p.epilogue = epilogue; p.act = act;
+  int nct = (N + BN2 - 1) / BN2;
+  int64_t grid = (int64_t)nct * ((M + BM2 - 1) / BM2 + E);
+  if (grid <= 0) return CSMOE_OK;
+  if (grid > 0x7fffffff) { csmoe_set_error("grouped_gemm: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
+  int rc;
+  if (b_layout == CSMOE_B_NK) {
+    if ((rc = set_lds2(gg8_kernel<KC, KC, 0, DEEP>))) return rc;
+    hipLaunchKernelGGL((gg8_kernel<KC, KC, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+  } else {
+    if ((rc = set_lds2(gg8_kernel<KC, KM, 0, DEEP>))) return rc;
+    hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+  }
+  CSMOE_CHECK_LAUNCH("grouped_gemm(bf16 v2)");
+  return CSMOE_OK;
+}
+
+int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
+              void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st) {
+  FastArgs p{};
+  p.single_M = single_M; p.single_C = single_C;
+  p.R = A; p.ld_r = lda; p.Cflat = B; p.ld_c = ldb; p.offsets = offsets; p.E = E; p.NR = Na; p.NC = Nb;
+  p.out_ptrs = c_ptrs; p.ldc = ldc; p.accumulate = accumulate; p.out_f32 = (out_dtype == CSMOE_F32);
+  int64_t grid = (int64_t)E * ((Na + BM2 - 1) / BM2) * ((Nb + BN2 - 1) / BN2);
+  if (grid <= 0) return CSMOE_OK;
+  if (grid > 0x7fffffff) { csmoe_set_error("grouped_wgrad: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
+  int rc;
+  if ((rc = set_lds2(gg8_kernel<KM, KM, 1, DEEP>))) return rc;
+  hipLaunchKernelGGL((gg8_kernel<KM, KM, 1, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+  CSMOE_CHECK_LAUNCH("grouped_wgrad(bf16 v2)");
+  return CSMOE_OK;
+}

@@ -1,0 +1,161 @@
+// Shared pieces of the bf16 grouped-GEMM kernels: argument block, buffer descriptors, the two swizzled 16 KiB LDS tile
+// images (KC / KM, see gemm_bf16.hip) with their LDS-DMA fill and fragment reads, and the 8-wide activation helpers.
+#pragma once
+#include "common.h"
+
+namespace ggt {
+
+constexpr unsigned OOB = 0x80000000u;       // any offset >= num_records reads as zero
+constexpr int TILE_B = 16384;               // one 128x64 (KC) / 64x128 (KM) bf16 tile image
+
+enum { KC = 0, KM = 1 };
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct FastArgs {
+  // row operand ("tokens" / wgrad A): [*, ld_r]; col operand (weights / wgrad B)
+  const void* R; int64_t ld_r;
+  const void* Cflat; int64_t ld_c;            // wgrad col operand (flat [M, Nb])
+  const void* const* c_ptrs_in;               // row-space: per-expert weight pointers
+  const void* const* bias_ptrs;
+  const int32_t* offsets; int E;
+  int single_M; const void* single_B; const void* single_bias; void* single_C;
+  int NR;      // row-space: unused;  wgrad: Na (output rows)
+  int NC;      // output columns (N or Nb)
+  int Kd;      // row-space reduction length
+  void* C; void* C2; const void* aux; int64_t ldc;
+  void* const* out_ptrs;                      // wgrad outputs
+  int epilogue, act, accumulate, out_f32;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+
+// ---- LDS-DMA fill of one 16 KiB tile image: NJ wave-instructions per wave (NJ * waves = 16) ----------------------
+// KC: tile rows are operand rows (stride ld_bytes), 64 reduction elements per row starting at red0.
+// KM: tile rows are 64 reduction rows, 128 operand columns starting at col0.
+template <int KIND, int NJ>
+__device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, const unsigned (&vbase)[NJ],
+                                         const int (&aux)[NJ], int red0, int red_len, unsigned ld_bytes, int wave) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    unsigned voff;
+    if (KIND == KC) {
+      voff = vbase[j] + (unsigned)red0 * 2u;            // aux[j] = first reduction element of this lane's chunk
+      if (red0 + aux[j] >= red_len) voff = OOB;
+    } else {
+      voff = vbase[j] + (unsigned)red0 * ld_bytes;      // vbase already OOB for out-of-range columns; rows past the
+    }                                                   // end of the reduction fall off num_records
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + (wave * NJ + j) * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+// one 1 KiB piece (wave-instruction) of an image: lets a caller interleave the NJ pieces with other work
+template <int KIND, int NJ>
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, unsigned vbase_j, int aux_j, int j,
+                                          int red0, int red_len, unsigned ld_bytes, int wave) {
+  unsigned voff;
+  if (KIND == KC) {
+    voff = vbase_j + (unsigned)red0 * 2u;
+    if (red0 + aux_j >= red_len) voff = OOB;
+  } else {
+    voff = vbase_j + (unsigned)red0 * ld_bytes;
+  }
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(lds_tile + (wave * NJ + j) * 1024), 16, voff, 0, 0, 0);
+}
+
+// per-lane, loop-invariant DMA source offsets.  Image row / column i (0..127) is fetched from source row / column
+//   src(i) = (i >> gshift) * gstride + (i & ((1 << gshift) - 1)) + sub
+// (identity for gshift = 7).  The v2 kernel uses it to build images out of the 64-row / 32-column strips each wave reads in
+// one phase.
+template <int KIND, int NJ>
+__device__ __forceinline__ void dma_setup(unsigned (&vbase)[NJ], int (&aux)[NJ], unsigned ld_bytes, int col0, int ncols,
+                                          int gshift, int gstride, int sub, int wave, int lane) {
+  const int gmask = (1 << gshift) - 1;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    int P = (wave * NJ + j) * 64 + lane;
+    if (KIND == KC) {
+      int r = P >> 3, pc = P & 7;
+      int c = pc ^ ((r >> 1) & 7);
+      int src = (r >> gshift) * gstride + (r & gmask) + sub;
+      vbase[j] = (unsigned)src * ld_bytes + (unsigned)c * 16u;
+      aux[j] = c * 8;
+    } else {
+      int k = P >> 4, pc = P & 15;
+      int f = (k & 3) | (((k >> 3) & 1) << 2);
+      int seg = (pc >> 1) ^ f;
+      int ic = seg * 16 + (pc & 1) * 8;
+      int col = col0 + (ic >> gshift) * gstride + (ic & gmask) + sub;
+      vbase[j] = (col < ncols) ? ((unsigned)k * ld_bytes + (unsigned)col * 2u) : OOB;
+      aux[j] = 0;
+    }
+  }
+}
+
+// ---- fragment reads ------------------------------------------------------------------------------------------------
+// KC: block b = 16 operand rows; returns the 8 reduction elements k = s*32 + 8*(lane>>4) .. +7 of row (lane&15)
+__device__ __forceinline__ bf16x8 frag_kc(const char* tile, int lane_off, int b, int s) {
+  return *(const bf16x8*)(tile + b * 2048 + (lane_off ^ (s << 6)));
+}
+// KM: column block cb; two transposed 4x16 reads
+__device__ __forceinline__ bf16x8 frag_km(const char* tile, int addr_cb, int s) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + addr_cb + s * 8192));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + addr_cb + s * 8192 + 1024));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// activation over 8 values, `switch` outside the element loop so each formula is emitted once
+__device__ __forceinline__ void act_fwd8(float (&v)[8], int act) {
+  switch (act) {
+    case CSMOE_ACT_RELU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_RELU);
+      break;
+    case CSMOE_ACT_GELU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_GELU);
+      break;
+    case CSMOE_ACT_GELU_TANH:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_GELU_TANH);
+      break;
+    case CSMOE_ACT_SILU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_SILU);
+      break;
+    default: break;
+  }
+}
+// h[j] <- act'(h[j])
+__device__ __forceinline__ void act_bwd8(float (&h)[8], int act) {
+  switch (act) {
+    case CSMOE_ACT_RELU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_RELU);
+      break;
+    case CSMOE_ACT_GELU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_GELU);
+      break;
+    case CSMOE_ACT_GELU_TANH:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_GELU_TANH);
+      break;
+    case CSMOE_ACT_SILU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_SILU);
+      break;
+    default:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = 1.f;
+      break;
+  }
+}
+
+}  // namespace ggt
