@@ -1,0 +1,169 @@
+"""Pretrain `competesmoe` (moe_pretrain_model/layers/moe/competesmoe.py:37-616): router policy on ordinary steps, dense
+competition (`competition_policy_mlp_faster`, :381-414) on the steps scheduled in `prob_flips_final[id_layer]`."""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .. import _lib as L
+from ..functional import DenseFFN, RouterSelect, SoftplusMean
+from .moe import MoE, op_dtype
+from .register import register_moe
+
+
+@register_moe("competesmoe")
+class CompeteSMoE(MoE):
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        args = self.args
+        self.warm_up = args.warm_up
+        self.rate_flip = args.rate_flip
+        self.current_steps = 0
+        self.step_warm = None
+        self.is_prob_flips = True
+        self.total_steps = args.stop_after
+        assert args.stop_after > 0, f"Warning: stop_after {args.stop_after} < 1, You must setting stop_after > 0"
+        self.prob_flips_final = {}
+        self.max_compete_in_iter = args.max_compete_in_iter
+        self.nb_diver = 0
+        self._flips_host = {}
+
+    # ------------------------------------------------------------------ schedule (:123-273)
+    def set_total_steps(self, id_layer=0):
+        self.step_warm = int(self.warm_up * self.total_steps)
+        flip_steps = self.total_steps - self.step_warm
+        self.flip_steps = flip_steps
+        if flip_steps <= 0:
+            raise ValueError("self.total_steps - self.step_warm must be greater than 0.")
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        device = self.w_gate.device
+        cap = self.max_compete_in_iter
+        if rank == 0:
+            rng_dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+            freq = [0] * flip_steps
+            for v in self.prob_flips_final.values():
+                for i, b in enumerate(v.tolist()):
+                    freq[i] += int(b)
+            cur = [False] * flip_steps
+            for i in range(flip_steps):
+                if torch.rand(1, device=rng_dev).item() < self.rate_flip:
+                    if freq[i] < cap:
+                        cur[i] = True
+                        freq[i] += 1
+                    else:
+                        found = False
+                        for j in range(i - 1, -1, -1):
+                            if freq[j] < cap and not cur[j]:
+                                cur[j], found = True, True
+                                freq[j] += 1
+                                break
+                        if not found:
+                            for j in range(i + 1, flip_steps):
+                                if freq[j] < cap and not cur[j]:
+                                    cur[j] = True
+                                    freq[j] += 1
+                                    break
+            probs_current = torch.tensor(cur, dtype=torch.bool, device=device)
+        else:
+            probs_current = torch.empty(flip_steps, dtype=torch.bool, device=device)
+        if world > 1:
+            dist.broadcast(probs_current, src=0)
+        self.prob_flips_final[id_layer] = probs_current
+        self._flips_host = {}
+        self.is_prob_flips = False
+        return self.prob_flips_final
+
+    def set_current_steps(self, step):
+        self.current_steps = step
+
+    def _competing(self, x, id_layer) -> bool:
+        if not x.requires_grad or self.step_warm is None or self.current_steps < self.step_warm:
+            return False
+        t = self.prob_flips_final[id_layer]
+        h = self._flips_host.get(id_layer)
+        if h is None or len(h) != t.numel():
+            h = self._flips_host[id_layer] = t.tolist()
+        return bool(h[self.current_steps - self.step_warm] == 1)
+
+    # ------------------------------------------------------------------ policies
+    def compute_gate(self, x):
+        a = self.args
+        if getattr(a, "is_cosine", False) and not getattr(a, "is_norm_weight", False):
+            return F.linear(F.normalize(x, p=2.0, dim=-1), F.normalize(self.w_gate, p=2.0, dim=-1))
+        if getattr(a, "is_norm_weight", False):
+            return F.linear(x, F.normalize(self.w_gate, p=2.0, dim=-1))
+        return super().compute_gate(x)
+
+    def router_policy(self, x, is_normal_mode=False):
+        assert not (getattr(self.args, "is_cosine", False) and getattr(self.args, "is_norm_weight", False)), \
+            "Can not active  both  Cosine and Norm Weigh. Just use one method - Cosine or Norm Weigh to Normalization"
+        gate_logits = self.compute_gate(x)
+        if getattr(self.args, "norm_sigmoid", False):
+            gate_softmax = F.softmax(gate_logits, dim=-1, dtype=torch.float32)
+            w, idx = torch.topk(gate_logits, self.num_selected)
+            w = torch.sigmoid(w / getattr(self.args, "scale_weight", 1.0))
+            w = w / torch.sum(w, dim=-1, keepdim=True).to(x.dtype)
+            return w, idx.int(), gate_softmax, gate_logits
+        weights, selected_experts, gate_softmax = self.topk_expert(gate_logits, x.dtype)
+        return weights, selected_experts, gate_softmax, gate_logits
+
+    def competition_policy_mlp_faster(self, x):
+        """relu(x @ keys[e]) @ values[e] for EVERY expert (dense GEMM kernels), affinity = mean softplus, top-K of the raw
+        affinities, renormalised weights, the K selected dense outputs for the diversity loss."""
+        B, N, D = x.shape
+        op = op_dtype(x)
+        x2 = x.reshape(-1, D).to(op)
+        outs = [DenseFFN.apply(x2, self.keys[e], None, self.values[e], None, self.act_code, L.B_KN) for e in range(self.n_experts)]
+        aff = torch.stack([SoftplusMean.apply(o) for o in outs], dim=-1)                 # [T,E] op dtype
+        asm, idx, w = RouterSelect.apply(aff, self.num_selected, L.SEL_RAW, False)
+        eo = torch.stack(outs, dim=1).view(B, N, self.n_experts, -1)
+        idx_l = idx.view(B, N, -1).long()
+        topk = torch.gather(eo, 2, idx_l.unsqueeze(-1).expand(B, N, self.num_selected, eo.size(-1)))
+        return w.view(B, N, -1), idx.view(B, N, -1), asm.view(B, N, -1), aff.view(B, N, -1), topk
+
+    def router_loss(self, gate_softmax, affinity_softmax):
+        return F.mse_loss(gate_softmax, affinity_softmax)
+
+    def experts_diversity_loss(self, expert_outputs):
+        eo = expert_outputs
+        B, N, K, D = eo.shape
+        nrm = F.normalize(eo, p=2, dim=-1).view(B * N, K, D)
+        sim = torch.bmm(nrm, nrm.transpose(1, 2)) * (1 - torch.eye(K, device=eo.device, dtype=eo.dtype))
+        self.nb_diver += (sim != 0).sum()
+        return sim.mean()
+
+    def compute_moe_main(self, x, selected_experts, weights):
+        return self.ffn(x, selected_experts, weights)
+
+    def forward(self, x, return_id_experts=False, return_full=True, *args, **kwargs):
+        id_layer = kwargs["id_layer"]
+        assert id_layer is not None, "Layer Id must to not None"
+        a = self.args
+        is_comp = self._competing(x, id_layer)
+        gate_weights, gate_selected_experts, gate_softmax, gate_logits = self.router_policy(x)
+        if is_comp:
+            aw, aidx, asm, aff, expert_outputs = self.competition_policy_mlp_faster(x)
+            out = self.compute_moe_main(x, aidx, aw)
+            div = self.experts_diversity_loss(expert_outputs)
+            self.add_reg(lambda: div * a.balance_loss_coef_comp / 2, self.name_moe + "_comp_diver_loss")
+            if a.balance_affinity:
+                bexp = self.entropy_balance(asm)
+                self.add_reg(lambda: bexp * a.balance_loss_coef_comp / 2, f"{self.name_moe}_comp_ebalance")
+            il = aidx.long()
+            if a.in_topk:
+                rl = self.router_loss(affinity_softmax=torch.gather(asm, -1, il).detach(), gate_softmax=torch.gather(gate_softmax, -1, il))
+            elif a.hybrid or a.tribrid:
+                rl = self.router_loss(affinity_softmax=asm.detach(), gate_softmax=gate_softmax) + self.router_loss(
+                    affinity_softmax=torch.gather(asm, -1, il).detach(), gate_softmax=torch.gather(gate_softmax, -1, il)) * a.router_theta
+                if a.tribrid and not a.hybrid:
+                    gl = gate_selected_experts.long()
+                    rl = rl + self.router_loss(affinity_softmax=torch.gather(asm, -1, gl).detach(),
+                                               gate_softmax=torch.gather(gate_softmax, -1, gl)) * a.router_theta
+            else:
+                rl = self.router_loss(affinity_softmax=asm.detach(), gate_softmax=gate_softmax)
+            self.add_reg(lambda: rl * a.router_loss_coef, f"{self.name_moe}_router_loss")
+        else:
+            out = self.compute_moe_main(x, gate_selected_experts, gate_weights)
+            bal = self.entropy_balance(gate_logits) * (a.balance_loss_coef / self.div)
+            self.add_reg(lambda: bal, f"{self.name_moe}_ebalance")
+        self._test_stats(gate_selected_experts, gate_weights, gate_softmax)
+        return self._finish(out, x)
