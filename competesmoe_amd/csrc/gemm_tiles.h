@@ -110,6 +110,32 @@ __device__ __forceinline__ bf16x8 frag_km(const char* tile, int addr_cb, int s) 
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// ---- fast GELU for the bf16 epilogues -------------------------------------------------------------------------------------
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below half a bf16 ulp), one v_exp + one v_rcp: the OCML erff costs
+// ~50 instructions and made the bias+GELU epilogue ~30 % of a K=4096 tile (profiles/r01).  The fp32 path (gemm_generic.hip)
+// keeps the exact erff.
+__device__ __forceinline__ float erf_as(float x, float& e_out) {   // returns erf(x); e_out = exp(-x*x)
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float e = __expf(-ax * ax);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.f - p * t * e;
+  e_out = e;
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  float e;
+  return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752440f, e));
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  float e;   // exp(-x^2/2)
+  const float cdf = 0.5f * (1.f + erf_as(x * 0.70710678118654752440f, e));
+  return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
 // activation over 8 values, `switch` outside the element loop so each formula is emitted once
 __device__ __forceinline__ void act_fwd8(float (&v)[8], int act) {
   switch (act) {
@@ -119,7 +145,7 @@ __device__ __forceinline__ void act_fwd8(float (&v)[8], int act) {
       break;
     case CSMOE_ACT_GELU:
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_GELU);
+      for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]);
       break;
     case CSMOE_ACT_GELU_TANH:
 #pragma unroll
@@ -141,7 +167,7 @@ __device__ __forceinline__ void act_bwd8(float (&h)[8], int act) {
       break;
     case CSMOE_ACT_GELU:
 #pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_GELU);
+      for (int j = 0; j < 8; ++j) h[j] = gelu_grad_fast(h[j]);
       break;
     case CSMOE_ACT_GELU_TANH:
 #pragma unroll

@@ -435,6 +435,7 @@ __global__ void __launch_bounds__(256) combine_bwd_kernel(const T* dout, const T
 template <typename T, typename TOut>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* G, int64_t ldg, const int32_t* offsets, int single_M, int N,
                                                      void* const* out_ptrs, void* single_out) {
+  // generic (any N / alignment): lane = 4 columns, 4 waves split the rows
   __shared__ float part[4][256];
   const int e = blockIdx.y;
   const int r0 = offsets ? offsets[e] : 0, r1 = offsets ? offsets[e + 1] : single_M;
@@ -455,6 +456,43 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* G, int64_t ldg, co
     float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
     TOut* o = (TOut*)(out_ptrs ? out_ptrs[e] : single_out);
     DT<TOut>::st(o + c, v);
+  }
+}
+
+// bf16, N % 8 == 0, 16-B aligned rows: lane = 8 columns (16 B), a wave covers 512 columns, 4 waves split the rows and keep
+// 4 row loads in flight each
+template <typename TOut>
+__global__ void __launch_bounds__(256) colsum_bf16x8_kernel(const bf16* G, int64_t ldg, const int32_t* offsets, int single_M, int N,
+                                                            void* const* out_ptrs, void* single_out) {
+  __shared__ float part[4][512];
+  const int e = blockIdx.y;
+  const int r0 = offsets ? offsets[e] : 0, r1 = offsets ? offsets[e + 1] : single_M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 512 + lane * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    int r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {
+      bf16x8 v0 = *(const bf16x8*)(G + (int64_t)r * ldg + c0);
+      bf16x8 v1 = *(const bf16x8*)(G + (int64_t)(r + 4) * ldg + c0);
+      bf16x8 v2 = *(const bf16x8*)(G + (int64_t)(r + 8) * ldg + c0);
+      bf16x8 v3 = *(const bf16x8*)(G + (int64_t)(r + 12) * ldg + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += ((float)v0[j] + (float)v1[j]) + ((float)v2[j] + (float)v3[j]);
+    }
+    for (; r < r1; r += 4) {
+      bf16x8 v0 = *(const bf16x8*)(G + (int64_t)r * ldg + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += (float)v0[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[wave][lane * 8 + j] = s[j];
+  __syncthreads();
+  TOut* o = (TOut*)(out_ptrs ? out_ptrs[e] : single_out);
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int c = blockIdx.x * 512 + i;
+    if (c < N) DT<TOut>::st(o + c, part[0][i] + part[1][i] + part[2][i] + part[3][i]);
   }
 }
 
@@ -607,6 +645,15 @@ int k_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int sing
              void* single_out, int dtype, int out_dtype, hipStream_t st) {
   if (N == 0 || E == 0) return CSMOE_OK;
   dim3 grid((N + 255) / 256, E), block(256);
+  if (dtype == CSMOE_BF16 && N % 8 == 0 && ldg % 8 == 0 && ((uintptr_t)G & 15) == 0) {
+    dim3 g8((N + 511) / 512, E);
+    if (out_dtype == CSMOE_F32)
+      hipLaunchKernelGGL((colsum_bf16x8_kernel<float>), g8, block, 0, st, (const bf16*)G, ldg, offsets, single_M, N, out_ptrs, single_out);
+    else
+      hipLaunchKernelGGL((colsum_bf16x8_kernel<bf16>), g8, block, 0, st, (const bf16*)G, ldg, offsets, single_M, N, out_ptrs, single_out);
+    CSMOE_CHECK_LAUNCH("grouped_colsum");
+    return CSMOE_OK;
+  }
   if (dtype == CSMOE_F32)
     hipLaunchKernelGGL((colsum_kernel<float, float>), grid, block, 0, st, (const float*)G, ldg, offsets, single_M, N, out_ptrs,
                        single_out);

@@ -19,6 +19,29 @@ def _flip(layout: int) -> int:
 
 
 # ======================================================================================================== gate
+_CHUNK_OFFSETS = {}
+
+
+def _chunked_dense_wgrad(a: torch.Tensor, b: torch.Tensor, out_dtype) -> torch.Tensor:
+    """a^T b for a long, skinny reduction ([T,E]^T [T,D], T >> E): a single output tile row would occupy E*D/(128*128) CUs
+    only, so the T rows are cut into chunks that the grouped weight-gradient kernel treats as pseudo-experts (fp32
+    partials, deterministic), followed by one small sum."""
+    T, Na = a.shape
+    Nb = b.shape[1]
+    P = max(1, min(32, T // 1024))
+    if P == 1:
+        return ops.dense_wgrad(a, b, out_dtype=out_dtype)
+    key = (T, P, a.device)
+    off = _CHUNK_OFFSETS.get(key)
+    if off is None:
+        step = (T + P - 1) // P
+        off = _CHUNK_OFFSETS[key] = torch.clamp(torch.arange(P + 1, dtype=torch.int64) * step, max=T).int().to(a.device)
+    part = torch.empty(P, Na, Nb, dtype=torch.float32, device=a.device)
+    ptrs = part.data_ptr() + torch.arange(P, device=a.device, dtype=torch.int64) * (Na * Nb * 4)
+    ops.grouped_wgrad(a, b, off, P, part, ptrs)
+    return part.sum(0).to(out_dtype)
+
+
 class GateLogits(torch.autograd.Function):
     """logits = x @ w_gate^T rounded to x.dtype -- `self.gate(x)` (moe_model/model/moe/smoe.py:42) /
     `F.linear(x, self.w_gate)` (moe_pretrain_model/layers/moe/moe.py:121)."""
@@ -41,7 +64,7 @@ class GateLogits(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.dense_gemm(dlogits, wg, L.B_KN)                   # [T,E] @ [E,D]
         if ctx.needs_input_grad[1]:
-            dw = ops.dense_wgrad(dlogits, x2, out_dtype=ctx.w_dtype)   # [E,D] = dlogits^T x
+            dw = _chunked_dense_wgrad(dlogits, x2, ctx.w_dtype)        # [E,D] = dlogits^T x
         return dx, dw
 
 
