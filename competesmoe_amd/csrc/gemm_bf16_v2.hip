@@ -35,7 +35,7 @@ constexpr int BUF_B = 4 * TILE_B;            // one K-tile buffer: R0, R1, C0, C
 constexpr int CT2_LD = BN2 + 4;              // fp32 epilogue staging row stride (floats); 128 rows per pass
 constexpr int LDS2_BYTES = 128 * CT2_LD * 4; // 133,120 B  (>= 2 * BUF_B = 131,072 B)
 
-enum { SHALLOW = 0, DEEP = 1 };
+enum { SHALLOW = 0, DEEP = 1, WIDE = 2 };
 
 template <int ROWK, int COLK, int MODE, int SCHED>
 __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
@@ -171,6 +171,94 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   const bool act3 = rows_here > 128 && cols_here > 128;    // C_hi x R_hi
   const bool act4 = rows_here > 128 && cols_here > 0;      // C_lo x R_hi
 
+  if constexpr (SCHED == WIDE) {
+    // TWO phases of 32 MFMA per K-tile (half the barriers of the 4-phase loop; all 8 row blocks stay in registers):
+    //     phase A: read CL, RL, RH(s)   issue CL,CH(s+1)   vmcnt(8)   MFMA C_lo x R_all
+    //     phase B: read CH(s)           issue RL,RH(s+2)   vmcnt(6)   MFMA C_hi x R_all
+    const bool actA = rows_here > 0 && cols_here > 0, actAh = rows_here > 128 && cols_here > 0;
+    const bool actB = rows_here > 0 && cols_here > 128, actBh = rows_here > 128 && cols_here > 128;
+    ISSUE_RL(0); ISSUE_RH(0); ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(1); ISSUE_RH(1);
+    WAIT_DMA(6);                                           // RL, RH, CL(0) landed
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < nk; ++s) {
+      const char* base = smem + (s & 1) * (4 * TILE_B);
+      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
+      bf16x8 fc[2][2], fr[8][2];
+      // ---- phase A
+      if (actA) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km(i_cl, km_c[cb], ks);
+      }
+      if (actA || actB) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km(i_rl, km_r[rb], ks);
+      }
+      if (actAh || actBh) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km(i_rh, km_r[rb], ks);
+      }
+      ISSUE_CL(s + 1); ISSUE_CH(s + 1);
+      WAIT_DMA(8);                                         // CH(s) landed
+      PHASE_SYNC_IN();
+      if (actA) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+      }
+      if (actAh) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 4; rb < 8; ++rb)
+              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+      }
+      PHASE_SYNC_OUT();
+      // ---- phase B
+      if (actB) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km(i_ch, km_c[cb], ks);
+      }
+      ISSUE_RL(s + 2); ISSUE_RH(s + 2);
+      WAIT_DMA(6);                                         // RL, RH, CL(s+1) landed
+      PHASE_SYNC_IN();
+      if (actB) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
+      }
+      if (actBh) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 4; rb < 8; ++rb)
+              acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
+      }
+      PHASE_SYNC_OUT();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
+  } else {
   // prologue: K-tile 0 complete; SHALLOW also the column images of K-tile 1, DEEP all of K-tile 1 except RH
   ISSUE_RL(0); ISSUE_CL(0); ISSUE_CH(0); ISSUE_RH(0);
   if (SCHED == DEEP) { ISSUE_RL(1); ISSUE_CL(1); ISSUE_CH(1); WAIT_DMA(10); }
@@ -236,6 +324,8 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
     PHASE_SYNC_OUT();
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
+
+  }
 
   // the zero-fill DMAs of the K-tiles past the end may still be writing LDS: drain before the staging tile reuses it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -332,6 +422,15 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   }
 }
 
+int sched_pref() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CSMOE_GEMM_SCHED");
+    v = e ? atoi(e) : WIDE;
+  }
+  return v;
+}
+
 template <typename K>
 int set_lds2(K kern) {
   static bool done = false;
@@ -358,12 +457,23 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
   if (grid <= 0) return CSMOE_OK;
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_gemm: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;
+  const bool wide = sched_pref() == WIDE;
   if (b_layout == CSMOE_B_NK) {
-    if ((rc = set_lds2(gg8_kernel<KC, KC, 0, DEEP>))) return rc;
-    hipLaunchKernelGGL((gg8_kernel<KC, KC, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+    if (wide) {
+      if ((rc = set_lds2(gg8_kernel<KC, KC, 0, WIDE>))) return rc;
+      hipLaunchKernelGGL((gg8_kernel<KC, KC, 0, WIDE>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+    } else {
+      if ((rc = set_lds2(gg8_kernel<KC, KC, 0, DEEP>))) return rc;
+      hipLaunchKernelGGL((gg8_kernel<KC, KC, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+    }
   } else {
-    if ((rc = set_lds2(gg8_kernel<KC, KM, 0, DEEP>))) return rc;
-    hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+    if (wide) {
+      if ((rc = set_lds2(gg8_kernel<KC, KM, 0, WIDE>))) return rc;
+      hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, WIDE>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+    } else {
+      if ((rc = set_lds2(gg8_kernel<KC, KM, 0, DEEP>))) return rc;
+      hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+    }
   }
   CSMOE_CHECK_LAUNCH("grouped_gemm(bf16 v2)");
   return CSMOE_OK;
@@ -379,8 +489,13 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
   if (grid <= 0) return CSMOE_OK;
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_wgrad: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;
-  if ((rc = set_lds2(gg8_kernel<KM, KM, 1, DEEP>))) return rc;
-  hipLaunchKernelGGL((gg8_kernel<KM, KM, 1, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+  if (sched_pref() == WIDE) {
+    if ((rc = set_lds2(gg8_kernel<KM, KM, 1, WIDE>))) return rc;
+    hipLaunchKernelGGL((gg8_kernel<KM, KM, 1, WIDE>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+  } else {
+    if ((rc = set_lds2(gg8_kernel<KM, KM, 1, DEEP>))) return rc;
+    hipLaunchKernelGGL((gg8_kernel<KM, KM, 1, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
+  }
   CSMOE_CHECK_LAUNCH("grouped_wgrad(bf16 v2)");
   return CSMOE_OK;
 }

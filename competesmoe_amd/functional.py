@@ -38,7 +38,7 @@ def _chunked_dense_wgrad(a: torch.Tensor, b: torch.Tensor, out_dtype) -> torch.T
         off = _CHUNK_OFFSETS[key] = torch.clamp(torch.arange(P + 1, dtype=torch.int64) * step, max=T).int().to(a.device)
     part = torch.empty(P, Na, Nb, dtype=torch.float32, device=a.device)
     ptrs = part.data_ptr() + torch.arange(P, device=a.device, dtype=torch.int64) * (Na * Nb * 4)
-    ops.grouped_wgrad(a, b, off, P, part, ptrs)
+    ops.grouped_wgrad(a, b, off, P, part, ptrs, tag="gate_wgrad")
     return part.sum(0).to(out_dtype)
 
 

@@ -204,11 +204,11 @@ def dense_gemm(A: torch.Tensor, B: torch.Tensor, b_layout: int, bias: Optional[t
 
 
 def grouped_wgrad(A: torch.Tensor, B: torch.Tensor, offsets: torch.Tensor, E: int, out: torch.Tensor,
-                  out_ptrs: torch.Tensor, accumulate: bool = False, force_generic: bool = False):
+                  out_ptrs: torch.Tensor, accumulate: bool = False, force_generic: bool = False, tag: str = "grouped_wgrad_tn"):
     """out[e] = A_e^T @ B_e for every expert; `out` is [E, Na, Nb] (or any buffer the pointers index)."""
     M, Na = A.shape
     Nb = B.shape[1]
-    with _timed("grouped_wgrad_tn", 2.0 * M * Na * Nb):
+    with _timed(tag, 2.0 * M * Na * Nb):
         L.check(lib.csmoe_grouped_wgrad(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), offsets.data_ptr(), E, M, Na, Nb,
                                         out_ptrs.data_ptr(), Nb, _dt(A), _dt(out), int(accumulate), int(force_generic), _stream()),
                 "grouped_wgrad")
