@@ -350,3 +350,25 @@ def pretrain_dense_affinity(x, keys, values, act, k, x_dtype):
     eo = eo.reshape(B, N, *eo.shape[1:])
     topk_out = torch.gather(eo, 2, idx.unsqueeze(-1).expand(B, N, k, eo.size(-1)))
     return w, idx, asm, aff, topk_out
+
+
+def pretrain_deepseek_forward(x, w_gate, keys, values, keys_shared, values_shared, k, mode: str, op_dtype, x_dtype):
+    """DeepSeekV2.forward (moe_pretrain_model/layers/moe/deepseekv2.py:135-181: top-k of the logits, softmax over the K)
+    and DeepSeekV3.forward (deepseekv3.py:142-190: top-k of sigmoid(logits), w / (sum + 1e-20)), both plus the always-on shared
+    expert (a 1-expert cvmm with an all-zero selection and unit weight = a dense FFN).  Returns (out, gate_logits)."""
+    B, N, D = x.shape
+    xx = x.to(op_dtype)
+    lg = F.linear(xx, w_gate.to(op_dtype))
+    if mode == "deepseekv2":
+        idx = topk_lowest_index(lg.detach().float(), k)[1]
+        w = F.softmax(torch.gather(lg, -1, idx), dim=-1).to(x_dtype)
+    else:
+        sg = torch.sigmoid(lg)
+        idx = topk_lowest_index(sg.detach().float(), k)[1]
+        w = torch.gather(sg, -1, idx)
+        w = w / (w.sum(dim=-1, keepdim=True) + 1e-20)
+    out = pretrain_ffn(x, idx, w, keys, values, "relu", op_dtype)
+    zero = torch.zeros(B, N, 1, dtype=torch.long)
+    one = torch.ones(B, N, 1)
+    shared = pretrain_ffn(x, zero, one, keys_shared, values_shared, "relu", op_dtype)
+    return out + shared, lg
