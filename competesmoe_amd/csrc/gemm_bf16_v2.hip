@@ -13,7 +13,9 @@
 // vmcnt so the loop never drains the DMA queue (guide §5 "Pipelining across barriers"):
 //     SHALLOW: P1 RL(s+1)  P2 RH(s+1)  P3 CL(s+2)  P4 CH(s+2), vmcnt(4) in P4      (2-4 images in flight)
 //     DEEP   : P1 RH(s+1)  P2 RL(s+2)  P3 CL(s+2)  P4 CH(s+2), vmcnt(10) in P1,P2,P4 (5-6 images = 80-96 KiB in flight)
-// Measured (profiles/r01): DEEP is best for the K-contiguous (nn.Linear) layout, SHALLOW for K-major images.
+//     WIDE   : TWO phases of 32 MFMA per K-tile (A: CL,RL,RH x C_lo; B: CH x C_hi), 2 images issued per phase, vmcnt(8)/(6)
+// Measured (profiles/r01): WIDE > DEEP > SHALLOW on every layout (half the barriers: +6..16 %); WIDE is the default,
+// CSMOE_GEMM_SCHED=0|1|2 selects one for A/B runs.
 // Row half 1 (waves 4-7, the SIMD partners of waves 0-3) runs half a phase behind: one hardware barrier is A for one group and
 // B for the other, so one group's ds_reads / DMA issue overlap its partners' MFMAs ("Two waves per SIMD" item 9 of the
 // microarch guide; +9 % here).  Safety under the stagger: reads are retired (lgkmcnt(0)) and the counted vmcnt is taken BEFORE
