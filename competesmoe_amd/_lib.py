@@ -33,6 +33,7 @@ SIGNATURES = {
     "csmoe_bin_workspace_bytes": (_l, [_i, _i]),
     "csmoe_bin_tokens": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),
     "csmoe_dispatch_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
+    "csmoe_dispatch_tokens": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "csmoe_dispatch_rows_bwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p]),
     "csmoe_combine": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "csmoe_combine_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

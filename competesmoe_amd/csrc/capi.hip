@@ -33,6 +33,7 @@ int k_router_select_bwd(const void*, int, int, int, int, int, int, const float*,
 int64_t k_bin_workspace_bytes(int n, int E);
 int k_bin_tokens(const int32_t*, int, int, int32_t*, int32_t*, int32_t*, int32_t*, void*, hipStream_t);
 int k_dispatch_rows(const void*, const int32_t*, int, void*, int, int, int, hipStream_t);
+int k_dispatch_tokens(const void*, const int32_t*, int, void*, int, int, int, hipStream_t);
 int k_combine(const void*, const int32_t*, const int32_t*, const float*, const void*, const void*, void*, int, int, int, int, int,
               hipStream_t);
 int k_combine_bwd(const void*, const void*, const int32_t*, const float*, void*, float*, int, int, int, int, hipStream_t);
@@ -147,6 +148,14 @@ int csmoe_dispatch_rows(const void* x, const int32_t* perm, int K, void* xs, int
   return k_dispatch_rows(x, perm, K, xs, n, row_bytes, vec_ok, (hipStream_t)stream);
 }
 
+int csmoe_dispatch_tokens(const void* x, const int32_t* slot_of, int K, void* xs, int T, int D, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && T >= 0 && D > 0, "dispatch_tokens: bad arguments");
+  CSMOE_CHECK_ARG(T == 0 || (x && slot_of && xs), "dispatch_tokens: null pointer");
+  int row_bytes = D * esize(dtype);
+  int vec_ok = ((((uintptr_t)x | (uintptr_t)xs) & 15) == 0 && (row_bytes & 15) == 0) ? 1 : 0;
+  return k_dispatch_tokens(x, slot_of, K, xs, T, row_bytes, vec_ok, (hipStream_t)stream);
+}
+
 int csmoe_dispatch_rows_bwd(const void* dxs, const int32_t* slot_of, int K, const void* add, void* dx, int T, int D, int dtype,
                             csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && K <= 64 && T >= 0 && D > 0, "dispatch_rows_bwd: bad arguments");
@@ -165,10 +174,10 @@ int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, con
 
 int csmoe_combine_bwd(const void* dout, const void* y, const int32_t* perm, const int32_t* slot_of, const float* w, void* dy,
                       float* dw, int T, int K, int D, int dtype, csmoe_stream_t stream) {
-  (void)slot_of;
+  (void)perm;
   CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && T >= 0 && D > 0, "combine_bwd: bad arguments");
-  CSMOE_CHECK_ARG(T == 0 || (dout && perm && dy), "combine_bwd: null pointer");
-  return k_combine_bwd(dout, y, perm, w, dy, dw, T * K, K, D, dtype, (hipStream_t)stream);
+  CSMOE_CHECK_ARG(T == 0 || (dout && slot_of && dy), "combine_bwd: null pointer");
+  return k_combine_bwd(dout, y, slot_of, w, dy, dw, T, K, D, dtype, (hipStream_t)stream);
 }
 
 int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,

@@ -279,6 +279,26 @@ __global__ void __launch_bounds__(256) dispatch_rows_kernel(const char* x, const
   }
 }
 
+// Token-major form: one wave per TOKEN copies its row to the K binned rows slot_of[t*K+k]; the source row is re-read from
+// L1/L2 for k > 0, so HBM sees it once (the row-major form above fetches x once per selected expert: 1.33x the bytes).
+__global__ void __launch_bounds__(256) dispatch_tokens_kernel(const char* x, const int32_t* slot_of, int K, char* xs, int T,
+                                                              int row_bytes, int vec_ok) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  const int nv = vec_ok ? (row_bytes >> 4) : 0;
+  for (int t = wave_g; t < T; t += nw) {
+    const i32x4* src = (const i32x4*)(x + (int64_t)t * row_bytes);
+    for (int k = 0; k < K; ++k) {
+      const int m = slot_of[(int64_t)t * K + k];
+      i32x4* dst = (i32x4*)(xs + (int64_t)m * row_bytes);
+      for (int i = lane; i < nv; i += 64) dst[i] = src[i];
+      for (int b = (nv << 4) + lane * 2; b < row_bytes; b += 128)
+        *(short*)((char*)dst + b) = *(const short*)((const char*)src + b);
+    }
+  }
+}
+
 // =====================================================================================================================
 // Combine  (moe.py:204 / cvmm.py:481-483) and the dispatch backward gather-sum (cvmm.py:544-545)
 // =====================================================================================================================
@@ -374,57 +394,60 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
   }
 }
 
-// combine backward: one wave per binned row m
+// combine backward: one wave per TOKEN, inner loop over its K slots (dout[t] comes from L1/L2 after the first slot, so HBM
+// reads it once): dy[slot] = round(w * dout[t]), dw[t,k] = <dout[t], y[slot]>
 template <typename T, int VEC>
-__global__ void __launch_bounds__(256) combine_bwd_kernel(const T* dout, const T* y, const int32_t* perm, const float* w, T* dy,
-                                                          float* dw, int n, int K, int D) {
+__global__ void __launch_bounds__(256) combine_bwd_kernel(const T* dout, const T* y, const int32_t* slot_of, const float* w, T* dy,
+                                                          float* dw, int Tn, int K, int D) {
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
-  for (int m = wave_g; m < n; m += nw) {
-    const int flat = perm[m];
-    const int t = flat / K;
-    const float wk = w ? w[flat] : 1.f;
-    float dot = 0.f;
-    for (int d0 = lane * VEC; d0 < D; d0 += 64 * VEC) {
-      const T* g = dout + (int64_t)t * D + d0;
-      float gv[VEC], yv[VEC];
-      if constexpr (VEC == 8) {
-        bf16x8 g8 = *(const bf16x8*)g;
+  for (int t = wave_g; t < Tn; t += nw) {
+    for (int k = 0; k < K; ++k) {
+      const int flat = t * K + k;
+      const int m = slot_of[flat];
+      const float wk = w ? w[flat] : 1.f;
+      float dot = 0.f;
+      for (int d0 = lane * VEC; d0 < D; d0 += 64 * VEC) {
+        const T* g = dout + (int64_t)t * D + d0;
+        float gv[VEC], yv[VEC];
+        if constexpr (VEC == 8) {
+          bf16x8 g8 = *(const bf16x8*)g;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) gv[v] = (float)g8[v];
-        if (y) {
-          bf16x8 y8 = *(const bf16x8*)(y + (int64_t)m * D + d0);
+          for (int v = 0; v < VEC; ++v) gv[v] = (float)g8[v];
+          if (y) {
+            bf16x8 y8 = *(const bf16x8*)(y + (int64_t)m * D + d0);
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) yv[v] = (float)y8[v];
+            for (int v = 0; v < VEC; ++v) yv[v] = (float)y8[v];
+          }
+          bf16x8 o8;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) o8[v] = (bf16)(gv[v] * wk);
+          *(bf16x8*)(dy + (int64_t)m * D + d0) = o8;
+        } else if constexpr (VEC == 4) {
+          f32x4 g4 = *(const f32x4*)g;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) gv[v] = g4[v];
+          if (y) {
+            f32x4 y4 = *(const f32x4*)(y + (int64_t)m * D + d0);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) yv[v] = y4[v];
+          }
+          *(f32x4*)(dy + (int64_t)m * D + d0) = f32x4{gv[0] * wk, gv[1] * wk, gv[2] * wk, gv[3] * wk};
+        } else {
+          gv[0] = DT<T>::ld(g);
+          if (y) yv[0] = DT<T>::ld(y + (int64_t)m * D + d0);
+          DT<T>::st(dy + (int64_t)m * D + d0, gv[0] * wk);
         }
-        bf16x8 o8;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) o8[v] = (bf16)(gv[v] * wk);
-        *(bf16x8*)(dy + (int64_t)m * D + d0) = o8;
-      } else if constexpr (VEC == 4) {
-        f32x4 g4 = *(const f32x4*)g;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) gv[v] = g4[v];
         if (y) {
-          f32x4 y4 = *(const f32x4*)(y + (int64_t)m * D + d0);
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) yv[v] = y4[v];
+          for (int v = 0; v < VEC; ++v) dot = fmaf(gv[v], yv[v], dot);
         }
-        *(f32x4*)(dy + (int64_t)m * D + d0) = f32x4{gv[0] * wk, gv[1] * wk, gv[2] * wk, gv[3] * wk};
-      } else {
-        gv[0] = DT<T>::ld(g);
-        if (y) yv[0] = DT<T>::ld(y + (int64_t)m * D + d0);
-        DT<T>::st(dy + (int64_t)m * D + d0, gv[0] * wk);
       }
-      if (y) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) dot = fmaf(gv[v], yv[v], dot);
+      if (y && dw) {
+        dot = wave_sum(dot);
+        if (lane == 0) dw[flat] = dot;
       }
-    }
-    if (y && dw) {
-      dot = wave_sum(dot);
-      if (lane == 0) dw[flat] = dot;
     }
   }
 }
@@ -593,6 +616,14 @@ int k_dispatch_rows(const void* x, const int32_t* perm, int K, void* xs, int n, 
   return CSMOE_OK;
 }
 
+int k_dispatch_tokens(const void* x, const int32_t* slot_of, int K, void* xs, int T, int row_bytes, int vec_ok, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  hipLaunchKernelGGL(dispatch_tokens_kernel, dim3(stride_grid(T)), dim3(256), 0, st, (const char*)x, slot_of, K, (char*)xs, T,
+                     row_bytes, vec_ok);
+  CSMOE_CHECK_LAUNCH("dispatch_tokens");
+  return CSMOE_OK;
+}
+
 int k_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias, const void* add,
               void* out, int T, int K, int D, int dtype, int mode, hipStream_t st) {
   if (T == 0) return CSMOE_OK;
@@ -619,6 +650,7 @@ int k_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const f
 
 int k_combine_bwd(const void* dout, const void* y, const int32_t* perm, const float* w, void* dy, float* dw, int n, int K, int D,
                   int dtype, hipStream_t st) {
+  // `perm` here is slot_of (token-major traversal); n = T
   if (n == 0) return CSMOE_OK;
   dim3 grid(stride_grid(n)), block(256);
   const bool al = (((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0;

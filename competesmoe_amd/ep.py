@@ -87,7 +87,7 @@ class EPFFN(torch.autograd.Function):
         x2 = x2.contiguous()
         T = x2.shape[0]
         bins = ops.bin_tokens(idx, E_global)
-        xs = ops.dispatch_rows(x2, bins)
+        xs = ops.dispatch_tokens(x2, bins)
         plan = make_plan(bins.counts, group)
         recv = a2a_rows(xs, plan.send_splits, plan.recv_splits, group)
         lb = ops.bin_tokens(local_expert_ids(plan).view(-1, 1), tab.E)

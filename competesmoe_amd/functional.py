@@ -113,7 +113,7 @@ class ExpertTable:
 def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias):
     T = x2.shape[0]
     bins = ops.bin_tokens(idx, tab.E)
-    xs = ops.dispatch_rows(x2, bins)
+    xs = ops.dispatch_tokens(x2, bins)
     ld1 = tab.D if tab.layout == L.B_NK else tab.F
     ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
     hpre, hact = ops.grouped_gemm(xs, tab.w1_ptrs, tab.layout, ld1, tab.F, bins.offsets, tab.E, bias_ptrs=tab.b1_ptrs,

@@ -147,6 +147,16 @@ def dispatch_rows(x2: torch.Tensor, bins: Bins) -> torch.Tensor:
     return xs
 
 
+def dispatch_tokens(x2: torch.Tensor, bins: Bins) -> torch.Tensor:
+    """Token-major dispatch: same xs as dispatch_rows, x fetched from HBM once per token."""
+    T, D = x2.shape
+    xs = torch.empty(bins.n, D, dtype=x2.dtype, device=x2.device)
+    with _timed("dispatch_rows", (T + bins.n) * D * x2.element_size()):
+        L.check(lib.csmoe_dispatch_tokens(x2.data_ptr(), bins.slot_of.data_ptr(), bins.K, xs.data_ptr(), T, D, _dt(x2), _stream()),
+                "dispatch_tokens")
+    return xs
+
+
 def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
     D = dxs.shape[1]
     dx = torch.empty(T, D, dtype=dxs.dtype, device=dxs.device)

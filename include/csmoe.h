@@ -103,6 +103,9 @@ int csmoe_bin_tokens(const int32_t* idx, int n, int E, int32_t* counts, int32_t*
  *                                                             cvmm.py:114-119 remap_offs_am) */
 int csmoe_dispatch_rows(const void* x, const int32_t* perm, int K, void* xs, int n, int D, int dtype,
                         csmoe_stream_t stream);
+/* token-major dispatch (same result; reads every x row from HBM once): xs[slot_of[t*K+k], :] = x[t, :] */
+int csmoe_dispatch_tokens(const void* x, const int32_t* slot_of, int K, void* xs, int T, int D, int dtype,
+                          csmoe_stream_t stream);
 /* dispatch backward: dx[t,:] = sum_k dxs[slot_of[t*K+k], :] (+ add[t,:] if add != null)   (cvmm.py:544-545) */
 int csmoe_dispatch_rows_bwd(const void* dxs, const int32_t* slot_of, int K, const void* add, void* dx, int T, int D,
                             int dtype, csmoe_stream_t stream);

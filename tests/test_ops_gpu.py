@@ -55,6 +55,7 @@ def test_dispatch_and_bwd(T, K, E, D, dtype):
     x = torch.randn(T, D, device=DEV).to(dtype)
     xs = ops.dispatch_rows(x, b)
     assert torch.equal(xs, x[(b.perm // K).long()])
+    assert torch.equal(ops.dispatch_tokens(x, b), xs)
     # backward: gather-sum of K rows per token (fp32 sum, one rounding)
     dxs = torch.randn(T * K, D, device=DEV).to(dtype)
     add = torch.randn(T, D, device=DEV).to(dtype)
