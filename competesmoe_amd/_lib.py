@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcsmoe_hip.so")
+LIB_PATH = os.environ.get("CSMOE_LIB") or os.path.join(_HERE, "lib", "libcsmoe_hip.so")   # CSMOE_LIB: A/B builds only
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_SILU = 0, 1, 2, 3, 4

@@ -106,3 +106,55 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return base + (id >> 3);
 }
+
+// Wave-parallel tile lookup for the grouped GEMMs: virtual tile v (after the XCD remap) -> expert, its row range and the
+// tile's position.  Lane l handles expert l (+64, +128, ...): one batch of offset loads and a 6-step shuffle scan replace a
+// serial walk over E dependent scalar loads per workgroup.  Tiles are ordered (expert, column tile, row tile), row tile fastest.
+// Returns false when v is past the last tile.  All results are wave-uniform (broadcast from the owning lane).
+struct TilePos { int e, o0, o1, mt, nt; };
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ int grouped_total_tiles(const int32_t* offsets, int E, int single_M, int BMt, int nct, int lane) {
+  int total = 0;
+  for (int base = 0; base < E; base += 64) {
+    int e = base + lane;
+    int cnt = 0;
+    if (e < E) cnt = offsets ? (offsets[e + 1] - offsets[e]) : single_M;
+    int tiles = ((cnt + BMt - 1) / BMt) * nct;
+    tiles = wave_incl_scan(tiles, lane);
+    total += __shfl(tiles, 63, 64);
+  }
+  return total;
+}
+__device__ __forceinline__ bool grouped_find_tile(const int32_t* offsets, int E, int single_M, int BMt, int nct, int v, int lane,
+                                                  TilePos& out) {
+  int acc = 0;
+  for (int base = 0; base < E; base += 64) {
+    int e = base + lane;
+    int o0 = 0, o1 = 0;
+    if (e < E) { o0 = offsets ? offsets[e] : 0; o1 = offsets ? offsets[e + 1] : single_M; }
+    int mt_e = (o1 - o0 + BMt - 1) / BMt;
+    int incl = wave_incl_scan(mt_e * nct, lane) + acc;
+    unsigned long long hit = __ballot(incl > v);
+    if (hit) {
+      int src = __ffsll((long long)hit) - 1;
+      int excl = __shfl(incl - mt_e * nct, src, 64);
+      int mte = __shfl(mt_e, src, 64);
+      int local = v - excl;
+      out.e = base + src;
+      out.o0 = __shfl(o0, src, 64);
+      out.o1 = __shfl(o1, src, 64);
+      out.mt = local % mte;
+      out.nt = local / mte;
+      return true;
+    }
+    acc = __shfl(incl, 63, 64);
+  }
+  return false;
+}

@@ -41,24 +41,14 @@ __global__ void __launch_bounds__(256, 2) gg_fast_kernel(FastArgs p) {
   int e, row0 = 0, rows = 0, tr0 = 0, tc0 = 0, red_len;
   const int nct = (p.NC + BN - 1) / BN;
   if (MODE == 0) {
-    int total = 0;
-    for (int i = 0; i < p.E; ++i) total += ((p.offsets ? p.offsets[i + 1] - p.offsets[i] : p.single_M) + BM - 1) / BM;
-    total *= nct;
+    const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BM, nct, lane);
     if ((int)blockIdx.x >= total) return;
-    int v = xcd_remap(blockIdx.x, total);
-    int accb = 0;
-    e = 0;
-    int mt_e = 0, o0 = 0, o1 = 0;
-    for (int i = 0; i < p.E; ++i) {
-      o0 = p.offsets ? p.offsets[i] : 0; o1 = p.offsets ? p.offsets[i + 1] : p.single_M;
-      mt_e = (o1 - o0 + BM - 1) / BM;
-      if (v < accb + mt_e * nct) { e = i; break; }
-      accb += mt_e * nct;
-    }
-    int local = v - accb;
-    int mt = local % mt_e, nt = local / mt_e;
-    row0 = o0 + mt * BM; rows = min(BM, o1 - row0);
-    tc0 = nt * BN;
+    const int v = xcd_remap(blockIdx.x, total);
+    TilePos tp;
+    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM, nct, v, lane, tp)) return;
+    e = tp.e;
+    row0 = tp.o0 + tp.mt * BM; rows = min(BM, tp.o1 - row0);
+    tc0 = tp.nt * BN;
     red_len = p.Kd;
   } else {
     const int nrt = (p.NR + BM - 1) / BM;
