@@ -1,0 +1,134 @@
+"""GPU, BASELINE.json full sizes (T=32768, D=4096, F=11008, E=64, K=2, bf16): size-independent properties of the HIP path.
+The CPU oracle cannot run these sizes in seconds, so parity here is structural: round trips, linearity, sampled exact dot
+products against fp64, routing invariance, and agreement between independent kernels (v1 / v2 / generic)."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T, D, F_, E, K = 32768, 4096, 11008, 64, 2
+
+if torch.cuda.is_available():
+    from competesmoe_amd import ops, _lib as L
+
+
+@pytest.fixture(scope="module")
+def routed():
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(T, D, device=DEV, generator=g).bfloat16()
+    wg = (torch.randn(E, D, device=DEV, generator=g) * 0.02).bfloat16()
+    logits = ops.gate_logits(x, wg)
+    sm, idx, w = ops.router_select(logits, K, L.SEL_SOFTMAX, True)
+    bins = ops.bin_tokens(idx, E)
+    return x, logits, sm, idx, w, bins
+
+
+def test_router_properties_full_size(routed):
+    x, logits, sm, idx, w, bins = routed
+    # softmax rows sum to 1; selected values are the K largest, in descending order; weights renormalised
+    assert torch.allclose(sm.sum(-1), torch.ones(T, device=DEV), atol=1e-5)
+    v = torch.gather(sm, -1, idx.long())
+    assert bool((v[:, 0] >= v[:, 1]).all())
+    kth = v[:, -1:]
+    assert int((sm > kth).sum(-1).max()) <= K - 1          # nothing outside the selection beats the K-th value
+    assert bool((idx[:, 0] != idx[:, 1]).all())
+    den = v.sum(-1, keepdim=True).bfloat16().float()
+    assert torch.allclose(w, v / den, rtol=1e-6, atol=0)
+    # idempotence: selecting again on the same scores gives the same answer bit for bit
+    sm2, idx2, w2 = ops.router_select(logits, K, L.SEL_SOFTMAX, True)
+    assert torch.equal(idx, idx2) and torch.equal(w, w2) and torch.equal(sm, sm2)
+
+
+def test_binning_is_a_stable_permutation_full_size(routed):
+    x, logits, sm, idx, w, bins = routed
+    n = T * K
+    assert int(bins.offsets[-1]) == n and int(bins.counts.sum()) == n
+    assert torch.equal(torch.sort(bins.perm).values.long(), torch.arange(n, device=DEV))
+    assert torch.equal(bins.slot_of[bins.perm.long()].long(), torch.arange(n, device=DEV))
+    e_sorted = idx.flatten()[bins.perm.long()]
+    assert bool((e_sorted[1:] >= e_sorted[:-1]).all())                       # sortedness
+    same = e_sorted[1:] == e_sorted[:-1]
+    assert bool((bins.perm[1:][same] > bins.perm[:-1][same]).all())          # stability inside every expert
+    assert torch.equal(torch.bincount(idx.flatten().long(), minlength=E).int(), bins.counts)
+
+
+def test_dispatch_combine_round_trip_full_size(routed):
+    """combine(dispatch(x)) with the renormalised weights is x itself (weights sum to 1, identity experts)."""
+    x, logits, sm, idx, w, bins = routed
+    xs = ops.dispatch_tokens(x, bins)
+    assert torch.equal(xs, ops.dispatch_rows(x, bins))
+    back = ops.combine(xs, bins, idx, w, L.COMBINE_DOT, T)
+    assert (back.float() - x.float()).abs().max() <= 2 ** -6 * x.float().abs().max()   # (w0 + w1) x, w0+w1 = 1 +- bf16 rounding of the sum
+    ones = torch.ones_like(w)
+    dx = ops.dispatch_rows_bwd(xs, bins, T)                                   # gather-sum of K copies = K * x
+    assert torch.equal(dx.float(), (x.float() * K).bfloat16().float())
+    dy, dw = ops.combine_bwd(x, xs, bins, ones)
+    assert torch.equal(dy, xs)                                                # scatter of dout with unit weights
+    assert torch.allclose(dw[:, 0], (x.float() ** 2).sum(-1), rtol=1e-3)      # <x, x> per token
+
+
+def _sampled_rows_check(C, A, Bs, off, layout, nsamp, seed):
+    g = torch.Generator().manual_seed(seed)
+    M, N = C.shape
+    rows = torch.randint(0, M, (nsamp,), generator=g)
+    cols = torch.randint(0, N, (nsamp,), generator=g)
+    offc = off.cpu()
+    for r, c in zip(rows.tolist(), cols.tolist()):
+        e = int(torch.searchsorted(offc[1:].long(), torch.tensor(r), right=True))
+        bcol = Bs[e][c, :] if layout == 0 else Bs[e][:, c]
+        ref = float((A[r].double() * bcol.double()).sum())
+        got = float(C[r, c])
+        assert abs(got - ref) <= 2 ** -7 * abs(ref) + 2e-2, (r, c, got, ref)
+
+
+def test_grouped_gemm_full_size_linearity_and_samples(routed):
+    x, logits, sm, idx, w, bins = routed
+    g = torch.Generator(device=DEV).manual_seed(1)
+    xs = ops.dispatch_tokens(x, bins)
+    W1 = (torch.randn(E, F_, D, device=DEV, generator=g) * 0.02).bfloat16()
+    ar = torch.arange(E, device=DEV, dtype=torch.int64)
+    p1 = W1.data_ptr() + ar * (F_ * D * 2)
+    h = ops.grouped_gemm(xs, p1, L.B_NK, D, F_, bins.offsets, E)
+    _sampled_rows_check(h, xs, W1, bins.offsets, 0, 64, 3)
+    # linearity: GEMM(2a) = 2 GEMM(a) exactly (power-of-two scaling commutes with every rounding)
+    h2 = ops.grouped_gemm((xs.float() * 2).bfloat16(), p1, L.B_NK, D, F_, bins.offsets, E)
+    assert torch.equal(h2.float(), h.float() * 2)
+    # v1 (128^2) and v2 (256^2) kernels are independent implementations of the same sum: agree to bf16 rounding
+    sub = slice(0, int(bins.offsets[3]))
+    a = ops.grouped_gemm(xs[sub].contiguous(), p1, L.B_NK, D, F_, bins.offsets[:4].contiguous(), 3, force_generic=True)
+    assert (a.float() - h[sub].float()).abs().max() <= 2 ** -7 * h[sub].float().abs().max()
+    del h2, a
+    # weight gradient: sampled entries against fp64 dot products over the expert's rows; empty experts give zeros
+    gW = torch.empty(E, F_, D, device=DEV, dtype=torch.bfloat16)
+    ops.grouped_wgrad(h, xs, bins.offsets, E, gW, gW.data_ptr() + ar * (F_ * D * 2))
+    gen = torch.Generator().manual_seed(5)
+    for _ in range(24):
+        e = int(torch.randint(0, E, (1,), generator=gen)); i = int(torch.randint(0, F_, (1,), generator=gen)); j = int(torch.randint(0, D, (1,), generator=gen))
+        r0, r1 = int(bins.offsets[e]), int(bins.offsets[e + 1])
+        ref = float((h[r0:r1, i].double() * xs[r0:r1, j].double()).sum())
+        assert abs(float(gW[e, i, j]) - ref) <= 2 ** -7 * abs(ref) + 0.05
+    # checksum of checksums: sum over experts of dW equals the dense h^T xs (column sums compared)
+    tot = gW.float().sum(0).sum(0)                        # [D]
+    ref = (h.float().sum(1, keepdim=True) * xs.float()).sum(0)
+    assert torch.allclose(tot, ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item())
+
+
+def test_layer_routing_invariance_full_width():
+    """With identical experts the MoE output equals the dense FFN whatever the routing (weights sum to 1): exercises router,
+    binning, dispatch, both grouped GEMMs with bias + GELU, and combine at d_model 4096 / d_ff 11008 (E=8 to bound memory)."""
+    import types
+    from competesmoe_amd.moe import get_moe
+    Tn, En = 4096, 8
+    torch.manual_seed(0)
+    base = nn.Sequential(nn.Linear(D, F_), nn.GELU(), nn.Linear(F_, D))
+    with torch.no_grad():
+        for p in base.parameters():
+            p.normal_(0, 0.02)
+    layer = get_moe("smoe")(D, D, En, K, base, types.SimpleNamespace(balance_loss_coef=0.01, router_z_loss_coef=0.001))
+    layer = layer.to(DEV).bfloat16()
+    x = torch.randn(2, Tn // 2, D, device=DEV).bfloat16()
+    out, aux, _, _ = layer(x)
+    dense = layer.dense_expert(0, x)
+    err = (out.float() - dense.float()).norm() / dense.float().norm()
+    assert err <= 4e-3, float(err)
