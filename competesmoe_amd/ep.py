@@ -171,7 +171,7 @@ class EPSMoeLayer(MoeLayer):
                           selected_experts.reshape(B * N, -1).contiguous(), tab, self.num_of_experts, self.group,
                           L.COMBINE_SEQ, *params)
         output = out.view(B, N, -1)
-        auxiliary_loss = torch.tensor(0.0, device=x.device, dtype=x.dtype)
+        auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
         infor_aux = {}
         if x.requires_grad or return_id_experts:
             # per-rank losses on local tokens, as data-parallel training of the reference computes them

@@ -119,7 +119,7 @@ class CompeteSMoE(MoeLayer):
 
     def forward(self, x, return_id_experts=False, is_vision=False):
         gate_weights, gate_selected_experts, gate_softmax, gate_logits = self.router_policy(x)
-        auxiliary_loss = torch.tensor(0.0, device=x.device, dtype=x.dtype)
+        auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
         infor_aux = {}
         if self._competing(x):
             aff_w, aff_idx, aff_softmax, aff_scores, expert_outputs = self.competition_policy(x)

@@ -108,13 +108,15 @@ class MoeLayer(nn.Module):
     def balanceloss(self, selected_experts, gate_softmax):
         E = gate_softmax.shape[-1]
         density_1_proxy = gate_softmax.mean(dim=-2)
-        one_hot = nn.functional.one_hot(selected_experts[..., 0].long(), E).float()
+        # F.one_hot range-checks its input with .item() (a device sync that drains the launch queue): compare instead
+        top1 = selected_experts[..., 0].long().unsqueeze(-1)
+        one_hot = (top1 == torch.arange(E, device=top1.device)).float()
         density_1 = one_hot.mean(dim=-2)
         return (density_1_proxy * density_1).mean() * float(E ** 2)
 
     def combine_loss(self, selected_experts, gate_softmax, gate_logits, acitve_zloss=True):
         balance_loss = self.balanceloss(selected_experts=selected_experts, gate_softmax=gate_softmax)
-        router_z_loss = torch.tensor(0.0, device=gate_softmax.device)
+        router_z_loss = gate_softmax.new_zeros(())
         if acitve_zloss:
             router_z_loss = self.zloss(gate_logits, gate_softmax)
             auxiliary_loss = balance_loss * self.args.balance_loss_coef + router_z_loss * self.args.router_z_loss_coef

@@ -37,7 +37,7 @@ class MoEShareLayer(_SharedBase):
     def forward(self, x, return_id_experts=False, is_vision=False):
         routed, shared, selected_experts, gate_softmax, gate_logits = self._routed_and_shared(x)
         output = shared * 0.5 + routed * 0.5
-        auxiliary_loss = torch.tensor(0.0, device=x.device, dtype=x.dtype)
+        auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
         infor_aux = {}
         if x.requires_grad:
             auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(selected_experts, gate_softmax, gate_logits)

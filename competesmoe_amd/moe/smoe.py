@@ -18,7 +18,7 @@ class SMoeLayer(MoeLayer):
         gate_logits = self.gate_logits(x)
         weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
         output = self.compute_moe(selected_experts, weights, None, x)
-        auxiliary_loss = torch.tensor(0.0, device=x.device, dtype=x.dtype)
+        auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
         infor_aux = {}
         if x.requires_grad or return_id_experts:
             auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(selected_experts, gate_softmax, gate_logits)

@@ -152,7 +152,8 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
     def balanceloss(self, selected_experts, gate_softmax):
         E = self.num_of_experts
         proxy = gate_softmax.mean(dim=-2)
-        dens = F.one_hot(selected_experts[..., 0].long(), E).float().mean(dim=-2)
+        top1 = selected_experts[..., 0].long().unsqueeze(-1)
+        dens = (top1 == torch.arange(E, device=top1.device)).float().mean(dim=-2)      # no F.one_hot: it syncs the device
         return (proxy * dens).mean() * float(E ** 2)
 
     # ------------------------------------------------------------------ eval-time statistics (moe.py:163-182)
