@@ -1,6 +1,5 @@
-// Grouped expert GEMM v2 for gfx950 (row-space launches; the weight-gradient launch uses the persistent twin in
-// gemm_bf16_v2p.hip -- kept as two translation units because the persistent loop changes hipcc's register allocation of the
-// row-space kernels for the worse, measured -8..-11 %): 256x256 output tile, 512 threads (8 waves as 2 row-halves x 4 column-quarters, each
+// Persistent twin of gemm_bf16_v2.hip, used for the weight-gradient launch (44k short tiles): same kernel body inside a
+// per-CU tile loop.  Grouped expert GEMM v2 for gfx950: 256x256 output tile, 512 threads (8 waves as 2 row-halves x 4 column-quarters, each
 // wave 128x64 = 8x4 v_mfma_f32_16x16x32_bf16 accumulators), K-tile 64, 128 KiB of LDS, one workgroup per CU.
 //
 // LDS holds 4 kinds of 16 KiB images (the KC / KM images of gemm_tiles.h), two slots each (K-tile parity):
@@ -44,27 +43,46 @@ enum { SHALLOW = 0, DEEP = 1, WIDE = 2 };
 template <int ROWK, int COLK, int MODE, int SCHED>
 __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;       // row half, column quarter
+  const int lane0 = threadIdx.x & 63;
 
-  // ---------------- tile lookup ----------------
-  int e, row0 = 0, rows = 0, tr0 = 0, tc0 = 0, red_len;
+  // ---------------- persistent tile loop ----------------
+  // One workgroup per CU walks the tiles of its XCD's contiguous chunk of the virtual tile order (expert, column tile, row
+  // tile; row tile fastest): the 32 CUs of an XCD work on neighbouring tiles at any time (shared weight / activation panels in
+  // that XCD's L2), and no workgroup is re-dispatched between tiles (a 512-thread / 130 KiB workgroup launch per tile cost more
+  // than the tile lookup itself).
   const int nct = (p.NC + BN2 - 1) / BN2;
+  const int nrt_w = (p.NR + BM2 - 1) / BM2;
+  const int total = (MODE == 0) ? grouped_total_tiles(p.offsets, p.E, p.single_M, BM2, nct, lane0) : nrt_w * nct * p.E;
+  int v_begin, v_end, v_step;
+  if ((gridDim.x & 7) == 0) {
+    const int x = blockIdx.x & 7, q8 = total >> 3, r8 = total & 7;
+    const int cs = (x < r8) ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
+    v_begin = cs + (blockIdx.x >> 3); v_end = cs + q8 + (x < r8 ? 1 : 0); v_step = gridDim.x >> 3;
+  } else {
+    v_begin = blockIdx.x; v_end = total; v_step = gridDim.x;
+  }
+  // Row-space launches (MODE 0) stay one-tile-per-workgroup for now: in the persistent form hipcc needs > 256 VGPRs there
+  // (spills in the K-loop); the weight-gradient launch (44k short tiles, the one that gains most) is persistent.
+  constexpr bool PERSIST = (MODE == 1);
+  for (int v = v_begin, once = 0; v < v_end && (PERSIST || once == 0); v += v_step, ++once) {
+  // Everything derived from the thread id is tile-invariant; left visible, hipcc hoists ~70 such values out of this loop, keeps
+  // them live across the K-loop and spills.  An opaque copy per tile pins them inside the iteration (~100 VALU per tile).
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  __builtin_assume(tid >= 0 && tid < 512);       // give the range back: LDS offsets fold into ds_read immediates again
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;       // row half, column quarter
+  int e, row0 = 0, rows = 0, tr0 = 0, tc0 = 0, red_len;
   if (MODE == 0) {
-    const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BM2, nct, lane);
-    if ((int)blockIdx.x >= total) return;
-    const int v = xcd_remap(blockIdx.x, total);
     TilePos tp;
-    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM2, nct, v, lane, tp)) return;
+    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM2, nct, v, lane, tp)) break;
     e = tp.e;
     row0 = tp.o0 + tp.mt * BM2; rows = min(BM2, tp.o1 - row0);
     tc0 = tp.nt * BN2;
     red_len = p.Kd;
   } else {
-    const int nrt = (p.NR + BM2 - 1) / BM2;
-    const int per_e = nrt * nct;
-    int v = xcd_remap(blockIdx.x, per_e * p.E);
+    const int per_e = nrt_w * nct;
     e = v / per_e;
     int local = v - e * per_e;
     tr0 = (local / nct) * BM2; tc0 = (local % nct) * BN2;
@@ -329,8 +347,13 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 
   // ---------------- epilogue: two passes of 128 rows through an fp32 LDS tile ----------------
   float* stg = (float*)smem;
-  const int ec = (threadIdx.x & 31) * 8;       // this thread's 8 columns inside the 256-wide tile
-  const int er = threadIdx.x >> 5;             // 0..15
+  // The tile loop makes every lane-derived epilogue address loop-invariant; hipcc would hoist ~40 of them across the K-loop and
+  // spill.  An opaque copy of the thread id pins their computation here (a handful of VALU per tile).
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63, g_e = lane_e >> 4, i16_e = lane_e & 15;
+  const int ec = (tid_e & 31) * 8;             // this thread's 8 columns inside the 256-wide tile
+  const int er = tid_e >> 5;                   // 0..15
   const int ncol = tc0 + ec;
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (MODE == 0 && ncol < p.NC && (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT)) {
@@ -349,8 +372,8 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
       for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
-          const int m = wm * 64 + rb * 16 + i16;
-          const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
+          const int m = wm * 64 + rb * 16 + i16_e;
+          const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g_e;
           *(f32x4*)(stg + m * CT2_LD + n) = pass == 0 ? acc[cb][rb] : acc[cb][4 + rb];
         }
     }
@@ -415,6 +438,7 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
     }
     __syncthreads();
   }
+  }   // persistent tile loop
 }
 
 int sched_pref() {
@@ -424,6 +448,19 @@ int sched_pref() {
     v = e ? atoi(e) : WIDE;
   }
   return v;
+}
+
+int persistent_grid(int64_t tiles_upper) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+  }
+  const char* e = getenv("CSMOE_GEMM_PERSISTENT");
+  if (e && atoi(e) == 0) return (int)tiles_upper;        // A/B: one workgroup per tile
+  return (int)std::min<int64_t>(tiles_upper, ncu);
 }
 
 template <typename K>
@@ -439,37 +476,23 @@ int set_lds2(K kern) {
 
 }  // namespace
 
-int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
-                 const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
-                 const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
-                 hipStream_t st) {
+int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
+              void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st) {
   FastArgs p{};
-  p.single_M = M; p.single_B = single_B; p.single_bias = single_bias;
-  p.R = A; p.ld_r = lda; p.c_ptrs_in = b_ptrs; p.ld_c = ldb; p.bias_ptrs = bias_ptrs; p.offsets = offsets; p.E = E;
-  p.NC = N; p.Kd = Kd; p.C = C; p.C2 = C2; p.aux = aux; p.ldc = ldc; p.epilogue = epilogue; p.act = act;
-  int nct = (N + BN2 - 1) / BN2;
-  int64_t grid = (int64_t)nct * ((M + BM2 - 1) / BM2 + E);
+  p.single_M = single_M; p.single_C = single_C;
+  p.R = A; p.ld_r = lda; p.Cflat = B; p.ld_c = ldb; p.offsets = offsets; p.E = E; p.NR = Na; p.NC = Nb;
+  p.out_ptrs = c_ptrs; p.ldc = ldc; p.accumulate = accumulate; p.out_f32 = (out_dtype == CSMOE_F32);
+  int64_t grid = (int64_t)E * ((Na + BM2 - 1) / BM2) * ((Nb + BN2 - 1) / BN2);
   if (grid <= 0) return CSMOE_OK;
-  if (grid > 0x7fffffff) { csmoe_set_error("grouped_gemm: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
+  if (grid > 0x7fffffff) { csmoe_set_error("grouped_wgrad: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;
-  const bool wide = sched_pref() == WIDE;
-  if (b_layout == CSMOE_B_NK) {
-    if (wide) {
-      if ((rc = set_lds2(gg8_kernel<KC, KC, 0, WIDE>))) return rc;
-      hipLaunchKernelGGL((gg8_kernel<KC, KC, 0, WIDE>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
-    } else {
-      if ((rc = set_lds2(gg8_kernel<KC, KC, 0, DEEP>))) return rc;
-      hipLaunchKernelGGL((gg8_kernel<KC, KC, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
-    }
+  if (sched_pref() == WIDE) {
+    if ((rc = set_lds2(gg8_kernel<KM, KM, 1, WIDE>))) return rc;
+    hipLaunchKernelGGL((gg8_kernel<KM, KM, 1, WIDE>), dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
   } else {
-    if (wide) {
-      if ((rc = set_lds2(gg8_kernel<KC, KM, 0, WIDE>))) return rc;
-      hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, WIDE>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
-    } else {
-      if ((rc = set_lds2(gg8_kernel<KC, KM, 0, DEEP>))) return rc;
-      hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
-    }
+    if ((rc = set_lds2(gg8_kernel<KM, KM, 1, DEEP>))) return rc;
+    hipLaunchKernelGGL((gg8_kernel<KM, KM, 1, DEEP>), dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
   }
-  CSMOE_CHECK_LAUNCH("grouped_gemm(bf16 v2)");
+  CSMOE_CHECK_LAUNCH("grouped_wgrad(bf16 v2)");
   return CSMOE_OK;
 }
