@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--skew", action="store_true", help="add +2.0 to 8 gate rows (Zipf-like load, BASELINE.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=2048)
+    ap.add_argument("--force-ep", action="store_true", help="use the expert-parallel layer even with one rank (smoke-tests the N>1 code path)")
     return ap.parse_args()
 
 
@@ -111,15 +112,26 @@ def main():
     dev = torch.device("cuda", local)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or a.force_ep:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29577")
+        # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from competesmoe_amd import ops
     T, D = a.tokens, a.d_model
     Bsz = max(1, T // a.seq)
     Nseq = T // Bsz
-    if world > 1:
+    if world > 1 or a.force_ep:
         assert a.experts % world == 0, "experts must divide over ranks"
         layer = make_layer(a, dev, dt, E_local=a.experts // world, seed=1 + rank)
     else:
@@ -201,7 +213,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -61,7 +61,8 @@ def make_plan(counts: torch.Tensor, group=None) -> EPPlan:
 def a2a_rows(rows: torch.Tensor, in_splits: List[int], out_splits: List[int], group=None) -> torch.Tensor:
     """Variable-size row exchange: peer p gets rows[sum(in[:p]) : sum(in[:p+1])]."""
     out = torch.empty(sum(out_splits), rows.shape[1], dtype=rows.dtype, device=rows.device)
-    dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    with ops._timed("ep_all_to_all", (rows.shape[0] + out.shape[0]) * rows.shape[1] * rows.element_size()):
+        dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
     return out
 
 

@@ -116,3 +116,26 @@ def test_ep_world1_rccl_equals_single_gpu(dt_name):
 @pytest.mark.parametrize("dt_name", ["fp32", "bf16"])
 def test_ep_world2_one_gpu_equals_single_gpu(dt_name):
     assert _launch(2, "gloo", dt_name) == {0: True, 1: True}
+
+
+def test_bench_script_runs_small_config_and_ep_path():
+    """bench.py end to end on a small layer: the single-GPU path and (with --force-ep, world size 1 over RCCL) the exact code
+    path the driver launches for N > 1.  One JSON line with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--tokens", "2048", "--seq", "512", "--d-model", "256", "--d-ff", "512",
+            "--experts", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    for extra in ([], ["--force-ep"]):
+        env = dict(os.environ, MASTER_PORT=str(_free_port()))
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline"):
+            assert k in d, k
+        assert d["value"] > 0 and d["n_gpus"] == 1 and d["config"]["workload"]
+        if extra:
+            assert "ep_all_to_all" in d["kernels"]
