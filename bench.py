@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--skew", action="store_true", help="add +2.0 to 8 gate rows (Zipf-like load, BASELINE.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=2048)
+    ap.add_argument("--competition", action="store_true", help="time the CompeteSMoE competition step (every expert dense + sparse recompute) instead of the sparse smoe step")
     ap.add_argument("--force-ep", action="store_true", help="use the expert-parallel layer even with one rank (smoke-tests the N>1 code path)")
     return ap.parse_args()
 
@@ -63,7 +64,16 @@ def make_layer(a, dev, dt, E_local=None, seed=1):
         for m in experts:
             for p in m.parameters():
                 p.normal_(0.0, 0.02, generator=g)
-    if E_local is None:
+    if E_local is None and a.competition:
+        args = types.SimpleNamespace(balance_loss_coef=0.01, router_z_loss_coef=0.001, rate_flip=1.0, warm_up=0.0,
+                                     max_compete_in_iter=8, router_loss_coef=0.01, diversity_loss_coef=0.01,
+                                     bal_comp_loss_coef=0.01, hybrid=False, router_theta=0.5, moe_name="competesmoe")
+        layer = get_moe("competesmoe")(D, D, E, K, experts, args)
+        layer.set_total_steps(16, 0, {})
+        layer.prob_flips = torch.ones_like(layer.prob_flips)      # compete on every step
+        layer._flips_host = None
+        layer.set_current_steps(1)
+    elif E_local is None:
         layer = get_moe("smoe")(D, D, E, K, experts, args)
     else:
         from competesmoe_amd.ep import EPSMoeLayer
@@ -199,7 +209,7 @@ def main():
             "metric": "MoE-layer fwd+bwd tokens/sec at d_model=4096, 64 experts top-2", "value": round(total_tokens * a.steps / el, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"single sparse-MoE layer (smoe routing), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
+            "config": {"workload": f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
                                    f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, Linear+bias/GELU experts, "
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
                        "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
