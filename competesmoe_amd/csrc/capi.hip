@@ -97,8 +97,8 @@ int csmoe_device_info(int* n_cu, int* lds_bytes, char* name, int name_len) {
 int csmoe_gate_logits(const void* x, const void* w_gate, void* logits, int T, int D, int E, int dtype, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype), "gate_logits: bad dtype %d", dtype);
   CSMOE_CHECK_ARG(T >= 0 && D > 0 && E > 0, "gate_logits: bad shape T=%d D=%d E=%d", T, D, E);
-  CSMOE_CHECK_ARG(x && w_gate && logits, "gate_logits: null pointer");
-  if (T == 0) return CSMOE_OK;
+  CSMOE_CHECK_ARG(w_gate && (T == 0 || (x && logits)), "gate_logits: null pointer");
+  if (T == 0) return CSMOE_OK;      // empty batch: zero-row buffers have no address
   hipStream_t st = (hipStream_t)stream;
   // one dense "expert" over all T rows: logits = x @ w_gate^T
   if (dtype == CSMOE_BF16 && gg_fast_rowspace_ok(D, D, E, T, E, D, x, logits))
@@ -114,6 +114,7 @@ int csmoe_router_select(const void* scores, int dtype, int T, int E, int K, int 
   CSMOE_CHECK_ARG(T >= 0 && E > 0 && E <= 1024, "router_select: E=%d out of range (1..1024)", E);
   CSMOE_CHECK_ARG(K > 0 && K <= E && K <= 64, "router_select: K=%d out of range (1..min(E,64))", K);
   CSMOE_CHECK_ARG(sel_mode >= 0 && sel_mode <= 3, "router_select: bad mode %d", sel_mode);
+  if (T == 0) return CSMOE_OK;
   CSMOE_CHECK_ARG(scores && idx && w, "router_select: null pointer");
   return k_router_select(scores, dtype, T, E, K, sel_mode, round_sum_bf16, softmax, idx, w, (hipStream_t)stream);
 }
@@ -124,6 +125,7 @@ int csmoe_router_select_bwd(const void* scores, int dtype, int T, int E, int K, 
   CSMOE_CHECK_ARG(dtype_ok(dtype), "router_select_bwd: bad dtype %d", dtype);
   CSMOE_CHECK_ARG(T >= 0 && E > 0 && E <= 1024 && K > 0 && K <= E && K <= 64, "router_select_bwd: bad shape");
   CSMOE_CHECK_ARG(sel_mode >= 0 && sel_mode <= 3, "router_select_bwd: bad mode %d", sel_mode);
+  if (T == 0) return CSMOE_OK;
   CSMOE_CHECK_ARG(scores && idx && w && dscores, "router_select_bwd: null pointer");
   CSMOE_CHECK_ARG(softmax || (sel_mode != CSMOE_SEL_SOFTMAX && !dsoftmax), "router_select_bwd: softmax required");
   return k_router_select_bwd(scores, dtype, T, E, K, sel_mode, round_sum_bf16, softmax, idx, w, dw, dsoftmax, dscores,
@@ -168,7 +170,7 @@ int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, con
   CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && K <= 64 && T >= 0 && D > 0, "combine: bad arguments (K<=64)");
   CSMOE_CHECK_ARG(mode >= 0 && mode <= 2, "combine: bad mode %d", mode);
   CSMOE_CHECK_ARG(T == 0 || (y && slot_of && w && out), "combine: null pointer");
-  CSMOE_CHECK_ARG(mode == CSMOE_COMBINE_DOT || idx, "combine: idx required for the sequential rounding rule");
+  CSMOE_CHECK_ARG(T == 0 || mode == CSMOE_COMBINE_DOT || idx, "combine: idx required for the sequential rounding rule");
   return k_combine(y, slot_of, idx, w, obias, nullptr, out, T, K, D, dtype, mode, (hipStream_t)stream);
 }
 
@@ -189,7 +191,7 @@ int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, in
   CSMOE_CHECK_ARG(b_layout == CSMOE_B_NK || b_layout == CSMOE_B_KN, "grouped_gemm: bad B layout %d", b_layout);
   CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && act >= 0 && act <= 4, "grouped_gemm: bad epilogue/act");
   CSMOE_CHECK_ARG(b_ptrs && offsets && (M == 0 || (A && C)), "grouped_gemm: null pointer");
-  CSMOE_CHECK_ARG(epilogue != CSMOE_EPI_ACTGRAD || aux, "grouped_gemm: ACTGRAD epilogue needs aux");
+  CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "grouped_gemm: ACTGRAD epilogue needs aux");
   CSMOE_CHECK_ARG(lda >= Kd && ldc >= N && ldb >= (b_layout == CSMOE_B_NK ? Kd : N), "grouped_gemm: leading dimension too small");
   if (M == 0) return CSMOE_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -209,7 +211,7 @@ int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, in
                      int force_generic, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && M >= 0 && N > 0 && Kd > 0, "dense_gemm: bad arguments");
   CSMOE_CHECK_ARG(M == 0 || (A && B && C), "dense_gemm: null pointer");
-  CSMOE_CHECK_ARG(epilogue != CSMOE_EPI_ACTGRAD || aux, "dense_gemm: ACTGRAD epilogue needs aux");
+  CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "dense_gemm: ACTGRAD epilogue needs aux");
   if (M == 0) return CSMOE_OK;
   hipStream_t st = (hipStream_t)stream;
   if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C)) {
@@ -257,7 +259,8 @@ int csmoe_dense_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, in
 int csmoe_grouped_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int N, void* const* out_ptrs, int dtype,
                          int out_dtype, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && dtype_ok(out_dtype) && E > 0 && N > 0, "grouped_colsum: bad arguments");
-  CSMOE_CHECK_ARG(G && offsets && out_ptrs, "grouped_colsum: null pointer");
+  // G may be null when every bin is empty (the row count lives in `offsets`, on the device)
+  CSMOE_CHECK_ARG(offsets && out_ptrs, "grouped_colsum: null pointer");
   return k_colsum(G, ldg, offsets, E, 0, N, out_ptrs, nullptr, dtype, out_dtype, (hipStream_t)stream);
 }
 

@@ -168,10 +168,10 @@ class EPSMoeLayer(MoeLayer):
         gate_logits = self.gate_logits(x)
         weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
         tab, params = self._expert_table(len(self.experts), x.dtype, x.device)
-        out = EPFFN.apply(x.reshape(B * N, D), weights.reshape(B * N, -1).contiguous(),
-                          selected_experts.reshape(B * N, -1).contiguous(), tab, self.num_of_experts, self.group,
+        out = EPFFN.apply(x.reshape(B * N, D), weights.reshape(B * N, weights.shape[-1]).contiguous(),
+                          selected_experts.reshape(B * N, selected_experts.shape[-1]).contiguous(), tab, self.num_of_experts, self.group,
                           L.COMBINE_SEQ, *params)
-        output = out.view(B, N, -1)
+        output = out.view(B, N, out.shape[-1])
         auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
         infor_aux = {}
         if x.requires_grad or return_id_experts:

@@ -102,7 +102,7 @@ class CompeteSMoE(MoeLayer):
         softmax fp32 + top-K on the RAW affinities + renormalisation in x.dtype (RouterSelect, SEL_RAW)."""
         B, N, D = x.shape
         outs = [self.dense_expert(i, x) for i in range(self.num_of_experts)]
-        aff = torch.stack([SoftplusMean.apply(o.reshape(B * N, -1)) for o in outs], dim=-1)      # [T,E] x.dtype
+        aff = torch.stack([SoftplusMean.apply(o.reshape(B * N, o.shape[-1])) for o in outs], dim=-1)      # [T,E] x.dtype
         scores = torch.sigmoid(aff) if getattr(self.args, "norm_sigmoid", False) else aff
         if getattr(self.args, "norm_sigmoid", False):
             asm = F.softmax(aff, dim=-1, dtype=torch.float32)
@@ -110,9 +110,10 @@ class CompeteSMoE(MoeLayer):
         else:
             asm, idx, w = RouterSelect.apply(scores, self.num_selected, L.SEL_RAW, False)
         expert_outputs = torch.stack(outs, dim=2)                                                   # [B,N,E,Dout]
-        idx_l = idx.view(B, N, -1).long()
+        idx_l = idx.view(B, N, self.num_selected).long()
         topk = torch.gather(expert_outputs, 2, idx_l.unsqueeze(-1).expand(B, N, self.num_selected, expert_outputs.size(-1)))
-        return w.view(B, N, -1), idx.view(B, N, -1), asm.view(B, N, -1), aff.view(B, N, -1), topk
+        E, K = self.num_of_experts, self.num_selected
+        return w.view(B, N, K), idx.view(B, N, K), asm.view(B, N, E), aff.view(B, N, E), topk
 
     def router_loss(self, gate_softmax, affinity_softmax):
         return F.mse_loss(gate_softmax, affinity_softmax)

@@ -136,7 +136,7 @@ class MoeLayer(nn.Module):
     # ------------------------------------------------------------------ router (moe.py:113-132; smoe.py:42-44)
     def gate_logits(self, x):
         B, N, D = x.shape
-        return GateLogits.apply(x.reshape(B * N, D), self.gate.weight).view(B, N, -1)
+        return GateLogits.apply(x.reshape(B * N, D), self.gate.weight).view(B, N, self.gate.weight.shape[0])
 
     def topk_expert(self, gate_logits, num_selected=None):
         """Returns (weights fp32 RENORMALISED, selected_experts int32, gate_softmax fp32).  The reference returns the
@@ -188,21 +188,21 @@ class MoeLayer(nn.Module):
         n_experts = n_experts or len(self.experts)
         tab, params = self._expert_table(n_experts, x.dtype, x.device)
         mode = L.COMBINE_SEQ_RW if weights_rounded else L.COMBINE_SEQ
-        idx2 = selected_experts.reshape(B * N, -1)
+        idx2 = selected_experts.reshape(B * N, selected_experts.shape[-1])
         if idx2.dtype != torch.int32:
             idx2 = idx2.int()
-        w2 = weights.reshape(B * N, -1)
+        w2 = weights.reshape(B * N, weights.shape[-1])
         if w2.dtype != torch.float32:
             w2 = w2.float()
         out = MoEFFNModules.apply(x.reshape(B * N, D), w2.contiguous(), idx2.contiguous(), tab, mode, *params)
-        return out.view(B, N, -1)
+        return out.view(B, N, out.shape[-1])
 
     def dense_expert(self, i: int, x):
         """experts[i](x) over all tokens (shared expert / competition pass)."""
         fc1, act, fc2 = parse_expert(self.experts[i])
         B, N, D = x.shape
         y = DenseFFN.apply(x.reshape(B * N, D), fc1.weight, fc1.bias, fc2.weight, fc2.bias, act, L.B_NK)
-        return y.view(B, N, -1)
+        return y.view(B, N, y.shape[-1])
 
     def forward(self, x, return_id_experts=False):
         gate_logits = self.gate_logits(x)
