@@ -145,6 +145,11 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   __builtin_amdgcn_s_barrier();                        \
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_setprio(1)
+  // epilogue barrier: LDS traffic only (__syncthreads() adds s_waitcnt vmcnt(0): a wait for the pass's own global stores)
+#define EPI_SYNC()                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+  __builtin_amdgcn_s_barrier();                        \
+  asm volatile("" ::: "memory")
 #define PHASE_SYNC_OUT()                               \
   __builtin_amdgcn_s_setprio(0);                       \
   __builtin_amdgcn_sched_barrier(0);                   \
@@ -186,19 +191,19 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km(i_cl, km_c[cb], ks);
+          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
       }
       if (actA || actB) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km(i_rl, km_r[rb], ks);
+          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
       }
       if (actAh || actBh) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km(i_rh, km_r[rb], ks);
+          for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
       }
       ISSUE_CL(s + 1); ISSUE_CH(s + 1);
       WAIT_DMA(8);                                         // CH(s) landed
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km(i_ch, km_c[cb], ks);
+          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
       }
       ISSUE_RL(s + 2); ISSUE_RH(s + 2);
       WAIT_DMA(6);                                         // RL, RH, CL(s+1) landed
@@ -272,13 +277,13 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fcl[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km(i_cl, km_c[cb], ks);
+        for (int ks = 0; ks < 2; ++ks) fcl[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
     }
     if (act1 || act2) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km(i_rl, km_r[rb], ks);
+        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
     }
     if (SCHED == DEEP) { ISSUE_RH(s + 1); WAIT_DMA(10); }   // CH(s) landed
     else               { ISSUE_RL(s + 1); }
@@ -291,7 +296,7 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fch[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km(i_ch, km_c[cb], ks);
+        for (int ks = 0; ks < 2; ++ks) fch[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
     }
     if (SCHED == DEEP) { ISSUE_RL(s + 2); WAIT_DMA(10); }   // RH(s) landed
     else               { ISSUE_RH(s + 1); }
@@ -304,7 +309,7 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km(i_rh, km_r[rb], ks);
+        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
     }
     ISSUE_CL(s + 2);
     PHASE_SYNC_IN();
@@ -354,7 +359,7 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
           *(f32x4*)(stg + m * CT2_LD + n) = pass == 0 ? acc[cb][rb] : acc[cb][4 + rb];
         }
     }
-    __syncthreads();
+    EPI_SYNC();
     if (ncol < p.NC) {
       if (MODE == 0) {
         const int rlim = min(128, rows - pass * 128);
@@ -413,7 +418,7 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
         }
       }
     }
-    __syncthreads();
+    EPI_SYNC();
   }
 }
 

@@ -1,30 +1,17 @@
-// Persistent twin of gemm_bf16_v2.hip, used for the weight-gradient launch (44k short tiles): same kernel body inside a
-// per-CU tile loop.  Grouped expert GEMM v2 for gfx950: 256x256 output tile, 512 threads (8 waves as 2 row-halves x 4 column-quarters, each
-// wave 128x64 = 8x4 v_mfma_f32_16x16x32_bf16 accumulators), K-tile 64, 128 KiB of LDS, one workgroup per CU.
-//
-// LDS holds 4 kinds of 16 KiB images (the KC / KM images of gemm_tiles.h), two slots each (K-tile parity):
-//     RL = rows  0..63  of both row halves      (what every wave reads in phase 1)      CL = columns  0..31 of the 4 quarters
-//     RH = rows 64..127 of both row halves      (phase 3)                               CH = columns 32..63 of the 4 quarters
-// Every K-tile s is 4 phases; a phase = {fragment ds_reads, issue ONE image by LDS-DMA (2 x 1 KiB per wave), counted vmcnt,
-// lgkmcnt(0), s_barrier A, 16 MFMA (a 64x32 quadrant of the wave tile over K=64), s_barrier B}; wave (wm, wn) owns rows
-// wm*64+0..63 of BOTH row images and columns wn*32+0..31 of BOTH column images, so each image is consumed in exactly one phase:
-//     phase 1: read CL,RL(s)   MFMA C_lo x R_lo        phase 3: read RH(s)    MFMA C_hi x R_hi
-//     phase 2: read CH(s)      MFMA C_hi x R_lo        phase 4: (C_lo kept)   MFMA C_lo x R_hi
-// Two DMA schedules (template SCHED), both re-filling a slot only after the phase that read it and waiting with a COUNTED
-// vmcnt so the loop never drains the DMA queue (guide §5 "Pipelining across barriers"):
-//     SHALLOW: P1 RL(s+1)  P2 RH(s+1)  P3 CL(s+2)  P4 CH(s+2), vmcnt(4) in P4      (2-4 images in flight)
-//     DEEP   : P1 RH(s+1)  P2 RL(s+2)  P3 CL(s+2)  P4 CH(s+2), vmcnt(10) in P1,P2,P4 (5-6 images = 80-96 KiB in flight)
-//     WIDE   : TWO phases of 32 MFMA per K-tile (A: CL,RL,RH x C_lo; B: CH x C_hi), 2 images issued per phase, vmcnt(8)/(6)
-// Measured (profiles/r01): WIDE > DEEP > SHALLOW on every layout (half the barriers: +6..16 %); WIDE is the default,
-// CSMOE_GEMM_SCHED=0|1|2 selects one for A/B runs.
-// Row half 1 (waves 4-7, the SIMD partners of waves 0-3) runs half a phase behind: one hardware barrier is A for one group and
-// B for the other, so one group's ds_reads / DMA issue overlap its partners' MFMAs ("Two waves per SIMD" item 9 of the
-// microarch guide; +9 % here).  Safety under the stagger: reads are retired (lgkmcnt(0)) and the counted vmcnt is taken BEFORE
-// barrier A, so whichever group is ahead can neither re-fill a slot the other still reads nor read an image the other has not
-// finished fetching.  K-tiles past the end are still "issued": their offsets are out of range, the buffer descriptor turns
-// them into zero-fills of slots nobody reads, which keeps the wait counts uniform.
-// In-kernel s_memtime stamps of this loop (diagnostic build, profiles/r01/gemm_v2_stamps.txt): per phase ~450 cycles of
-// read/issue/wait, ~380 of MFMA and ~170 of release latency per barrier -- an LDS-DMA issue costs its wave 100-185 cycles.
+// Persistent weight-gradient GEMM for gfx950: dW[e] = A[rows of e]^T @ B[rows of e]  (bf16 operands, fp32 accumulate).
+// Same 256x256 tile / 8 waves / K-tile 64 / WIDE two-phase schedule as the row-space kernel in gemm_bf16_v2.hip (see its
+// header for the image kinds, the half-phase stagger of waves 4-7 and the counted-vmcnt rules); what differs is the outer
+// structure.  The headline launch is 44k tiles of only ~16 K-tiles each, so what happens BETWEEN tiles matters as much as
+// the K-loop:
+//   * one workgroup per CU walks its XCD's contiguous chunk of the tile order (no re-dispatch of a 512-thread / 130 KiB
+//     workgroup per tile);
+//   * the epilogue stages the accumulators through the UPPER 64 KiB of LDS only (4 passes of 64 rows), so K-tile 0 of the NEXT
+//     tile (4 images, the parity-0 slots in the lower 64 KiB) is fetched by LDS-DMA while this tile is converted and stored:
+//     the first-byte latency of a tile no longer sits between two K-loops;
+//   * the wait for that prefetch is taken in the last pass, BEFORE its global stores are issued (vmcnt retires in order on
+//     gfx9: waiting later would also wait for the stores), and K-tile 1's row images are issued right after the pass's closing
+//     barrier, when the staging area (= the parity-1 slots) is dead.
+// Both operands are K-major ([rows, features]): KM images read with ds_read_b64_tr_b16.
 #include "gemm_tiles.h"
 #include <algorithm>
 #include <cstdlib>
@@ -34,127 +21,84 @@ using namespace ggt;
 namespace {
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
-constexpr int BUF_B = 4 * TILE_B;            // one K-tile buffer: R0, R1, C0, C1
-constexpr int CT2_LD = BN2 + 4;              // fp32 epilogue staging row stride (floats); 128 rows per pass
-constexpr int LDS2_BYTES = 128 * CT2_LD * 4; // 133,120 B  (>= 2 * BUF_B = 131,072 B)
+constexpr int CT2_LD = BN2 + 4;                       // fp32 staging row stride (floats)
+constexpr int STG_OFF = 4 * TILE_B;                   // staging tile = upper half (the parity-1 slots)
+constexpr int LDS2_BYTES = STG_OFF + 64 * CT2_LD * 4; // 132,096 B  (>= 8 * TILE_B = 131,072 B)
 
-enum { SHALLOW = 0, DEEP = 1, WIDE = 2 };
+struct TileW { int e, row0, red_len, tr0, tc0; };     // wave-uniform
+struct DmaW {
+  __amdgpu_buffer_rsrc_t rs_r, rs_c;
+  unsigned vb_rl[2], vb_rh[2], vb_cl[2], vb_ch[2];
+};
 
-template <int ROWK, int COLK, int MODE, int SCHED>
-__global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
+// Scalar (SMEM) load of 8 bytes from a wave-uniform address.  Written as asm because hipcc turns a plain load of the offsets /
+// pointer tables into a VECTOR load once the kernel also stores to global memory, and every use of such a load costs an
+// `s_waitcnt vmcnt(0)`: a wait for the prefetch DMA and for all earlier stores of the epilogue.  The tables are written before
+// the launch, so the scalar cache is coherent for them.
+__device__ __forceinline__ uint64_t sload_b64(const void* ptr) {
+  const uint64_t a = (uint64_t)ptr;
+  const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+  uint64_t r;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(u) : "memory");
+  return r;
+}
+
+__device__ __forceinline__ TileW tile_of(const FastArgs& p, int v, int nct, int per_e) {
+  TileW t;
+  int e = v / per_e;
+  int local = v - e * per_e;
+  int row0 = 0, red_len = p.single_M;
+  if (p.offsets) {
+    const uint64_t oo = sload_b64(p.offsets + e);          // offsets[e], offsets[e + 1]
+    row0 = (int)(unsigned)oo;
+    red_len = (int)(unsigned)(oo >> 32) - row0;
+  }
+  t.e = __builtin_amdgcn_readfirstlane(e);
+  t.row0 = __builtin_amdgcn_readfirstlane(row0);
+  t.red_len = __builtin_amdgcn_readfirstlane(red_len);
+  t.tr0 = __builtin_amdgcn_readfirstlane((local / nct) * BM2);
+  t.tc0 = __builtin_amdgcn_readfirstlane((local % nct) * BN2);
+  return t;
+}
+
+__device__ __forceinline__ DmaW dma_of(const FastArgs& p, const TileW& t, unsigned ldr_b, unsigned ldc_b, int wave, int lane) {
+  DmaW d;
+  int ax[2];
+  d.rs_r = make_rsrc((const char*)p.R + (int64_t)t.row0 * ldr_b, (unsigned)t.red_len * ldr_b);
+  d.rs_c = make_rsrc((const char*)p.Cflat + (int64_t)t.row0 * ldc_b, (unsigned)t.red_len * ldc_b);
+  dma_setup<KM, 2>(d.vb_rl, ax, ldr_b, t.tr0, p.NR, 7, 0, 0, wave, lane);
+  dma_setup<KM, 2>(d.vb_rh, ax, ldr_b, t.tr0, p.NR, 7, 0, 128, wave, lane);
+  dma_setup<KM, 2>(d.vb_cl, ax, ldc_b, t.tc0, p.NC, 7, 0, 0, wave, lane);
+  dma_setup<KM, 2>(d.vb_ch, ax, ldc_b, t.tc0, p.NC, 7, 0, 128, wave, lane);
+  return d;
+}
+
+__global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane0 = threadIdx.x & 63;
 
-  // ---------------- persistent tile loop ----------------
-  // One workgroup per CU walks the tiles of its XCD's contiguous chunk of the virtual tile order (expert, column tile, row
-  // tile; row tile fastest): the 32 CUs of an XCD work on neighbouring tiles at any time (shared weight / activation panels in
-  // that XCD's L2), and no workgroup is re-dispatched between tiles (a 512-thread / 130 KiB workgroup launch per tile cost more
-  // than the tile lookup itself).
   const int nct = (p.NC + BN2 - 1) / BN2;
-  const int nrt_w = (p.NR + BM2 - 1) / BM2;
-  const int total = (MODE == 0) ? grouped_total_tiles(p.offsets, p.E, p.single_M, BM2, nct, lane0) : nrt_w * nct * p.E;
+  const int nrt = (p.NR + BM2 - 1) / BM2;
+  const int per_e = nrt * nct;
+  const int total = per_e * p.E;
   int v_begin, v_end, v_step;
-  if ((gridDim.x & 7) == 0) {
+  if ((gridDim.x & 7) == 0) {                    // one contiguous chunk of the tile order per XCD (blocks id, id+8 share one)
     const int x = blockIdx.x & 7, q8 = total >> 3, r8 = total & 7;
     const int cs = (x < r8) ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
     v_begin = cs + (blockIdx.x >> 3); v_end = cs + q8 + (x < r8 ? 1 : 0); v_step = gridDim.x >> 3;
   } else {
     v_begin = blockIdx.x; v_end = total; v_step = gridDim.x;
   }
-  // Row-space launches (MODE 0) stay one-tile-per-workgroup for now: in the persistent form hipcc needs > 256 VGPRs there
-  // (spills in the K-loop); the weight-gradient launch (44k short tiles, the one that gains most) is persistent.
-  constexpr bool PERSIST = (MODE == 1);
-  for (int v = v_begin, once = 0; v < v_end && (PERSIST || once == 0); v += v_step, ++once) {
-  // Everything derived from the thread id is tile-invariant; left visible, hipcc hoists ~70 such values out of this loop, keeps
-  // them live across the K-loop and spills.  An opaque copy per tile pins them inside the iteration (~100 VALU per tile).
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  __builtin_assume(tid >= 0 && tid < 512);       // give the range back: LDS offsets fold into ds_read immediates again
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;       // row half, column quarter
-  int e, row0 = 0, rows = 0, tr0 = 0, tc0 = 0, red_len;
-  if (MODE == 0) {
-    TilePos tp;
-    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM2, nct, v, lane, tp)) break;
-    e = tp.e;
-    row0 = tp.o0 + tp.mt * BM2; rows = min(BM2, tp.o1 - row0);
-    tc0 = tp.nt * BN2;
-    red_len = p.Kd;
-  } else {
-    const int per_e = nrt_w * nct;
-    e = v / per_e;
-    int local = v - e * per_e;
-    tr0 = (local / nct) * BM2; tc0 = (local % nct) * BN2;
-    row0 = p.offsets ? p.offsets[e] : 0;
-    red_len = (p.offsets ? p.offsets[e + 1] : p.single_M) - row0;
-  }
-  e = __builtin_amdgcn_readfirstlane(e);
-  row0 = __builtin_amdgcn_readfirstlane(row0);
-  rows = __builtin_amdgcn_readfirstlane(rows);
-  tr0 = __builtin_amdgcn_readfirstlane(tr0);
-  tc0 = __builtin_amdgcn_readfirstlane(tc0);
-  red_len = __builtin_amdgcn_readfirstlane(red_len);
-
-  // ---------------- operand descriptors + per-lane DMA offsets of the 4 image kinds ----------------
+  if (v_begin >= v_end) return;
   const unsigned ldr_b = (unsigned)p.ld_r * 2u, ldc_b = (unsigned)p.ld_c * 2u;
-  __amdgpu_buffer_rsrc_t rs_r, rs_c;
-  unsigned vb_rl[2], vb_rh[2], vb_cl[2], vb_ch[2];
-  int ax_r[2], ax_c[2], ax_dummy[2];
-  // RL / RH = tile rows [0,128) / [128,256); CL / CH = tile columns [0,128) / [128,256): contiguous, fully coalesced images.
-  // Wave (wm, wn) owns rows {wm*64 + 0..63} of BOTH row images and columns {wn*32 + 0..31} of BOTH column images, i.e. four
-  // 64x32 blocks of the 256x256 tile, so every image is consumed in exactly one phase by all eight waves.
-  if (MODE == 0) {
-    rs_r = make_rsrc((const char*)p.R + (int64_t)row0 * ldr_b, (unsigned)rows * ldr_b);
-    dma_setup<KC, 2>(vb_rl, ax_r, ldr_b, 0, 0, 7, 0, 0, wave, lane);
-    dma_setup<KC, 2>(vb_rh, ax_dummy, ldr_b, 0, 0, 7, 0, 128, wave, lane);
-    const char* wb = (const char*)(p.c_ptrs_in ? p.c_ptrs_in[e] : p.single_B);
-    if (COLK == KC) {
-      int nrows = min(BN2, p.NC - tc0);
-      rs_c = make_rsrc(wb + (int64_t)tc0 * ldc_b, (unsigned)nrows * ldc_b);
-      dma_setup<KC, 2>(vb_cl, ax_c, ldc_b, 0, 0, 7, 0, 0, wave, lane);
-      dma_setup<KC, 2>(vb_ch, ax_dummy, ldc_b, 0, 0, 7, 0, 128, wave, lane);
-    } else {
-      rs_c = make_rsrc(wb, (unsigned)p.Kd * ldc_b);
-      dma_setup<KM, 2>(vb_cl, ax_c, ldc_b, tc0, p.NC, 7, 0, 0, wave, lane);
-      dma_setup<KM, 2>(vb_ch, ax_dummy, ldc_b, tc0, p.NC, 7, 0, 128, wave, lane);
-    }
-  } else {
-    rs_r = make_rsrc((const char*)p.R + (int64_t)row0 * ldr_b, (unsigned)red_len * ldr_b);
-    dma_setup<KM, 2>(vb_rl, ax_r, ldr_b, tr0, p.NR, 7, 0, 0, wave, lane);
-    dma_setup<KM, 2>(vb_rh, ax_dummy, ldr_b, tr0, p.NR, 7, 0, 128, wave, lane);
-    rs_c = make_rsrc((const char*)p.Cflat + (int64_t)row0 * ldc_b, (unsigned)red_len * ldc_b);
-    dma_setup<KM, 2>(vb_cl, ax_c, ldc_b, tc0, p.NC, 7, 0, 0, wave, lane);
-    dma_setup<KM, 2>(vb_ch, ax_dummy, ldc_b, tc0, p.NC, 7, 0, 128, wave, lane);
-  }
-
-  // ---------------- LDS read addressing ----------------
-  const int g = lane >> 4, i16 = lane & 15;
-  const int kc_lane = i16 * 128 + ((g ^ (i16 >> 1)) << 4);
-  const int q = i16 >> 2, pp = i16 & 3;
-  const int fk = q | ((g & 1) << 2);
-  // this wave's 16-row / 16-column blocks inside an image: R images blocks wm*4 + 0..3, C images blocks wn*2 + 0..1
-  const int r_blk0 = wm * 4, c_blk0 = wn * 2;
-  int km_r[4], km_c[2];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) km_r[b] = (8 * g + q) * 256 + (((r_blk0 + b) ^ fk) << 5) + pp * 8;
-#pragma unroll
-  for (int b = 0; b < 2; ++b) km_c[b] = (8 * g + q) * 256 + (((c_blk0 + b) ^ fk) << 5) + pp * 8;
-
-  f32x4 acc[4][8];   // [column block][row block]
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (red_len + BK2 - 1) / BK2;
+  const int dummy_ax[2] = {0, 0};
 
   // slot(kind, parity) = (parity * 4 + kind) * 16 KiB with kind RL=0, CL=1, CH=2, RH=3
 #define SLOT(kind, tile) (smem + ((((tile) & 1) * 4 + (kind)) * TILE_B))
-#define ISSUE_RL(tile) dma_tile<ROWK, 2>(rs_r, SLOT(0, tile), vb_rl, ax_r, (tile) * BK2, red_len, ldr_b, wave)
-#define ISSUE_CL(tile) dma_tile<COLK, 2>(rs_c, SLOT(1, tile), vb_cl, ax_c, (tile) * BK2, red_len, ldc_b, wave)
-#define ISSUE_CH(tile) dma_tile<COLK, 2>(rs_c, SLOT(2, tile), vb_ch, ax_c, (tile) * BK2, red_len, ldc_b, wave)
-#define ISSUE_RH(tile) dma_tile<ROWK, 2>(rs_r, SLOT(3, tile), vb_rh, ax_r, (tile) * BK2, red_len, ldr_b, wave)
+#define ISSUE_RL(D, T, tile) dma_tile<KM, 2>(D.rs_r, SLOT(0, tile), D.vb_rl, dummy_ax, (tile) * BK2, T.red_len, ldr_b, wave)
+#define ISSUE_CL(D, T, tile) dma_tile<KM, 2>(D.rs_c, SLOT(1, tile), D.vb_cl, dummy_ax, (tile) * BK2, T.red_len, ldc_b, wave)
+#define ISSUE_CH(D, T, tile) dma_tile<KM, 2>(D.rs_c, SLOT(2, tile), D.vb_ch, dummy_ax, (tile) * BK2, T.red_len, ldc_b, wave)
+#define ISSUE_RH(D, T, tile) dma_tile<KM, 2>(D.rs_r, SLOT(3, tile), D.vb_rh, dummy_ax, (tile) * BK2, T.red_len, ldr_b, wave)
 #define WAIT_DMA(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
   // barrier A closes a phase's read/issue section (reads retired, counted DMA wait taken), barrier B its MFMA section
 #define PHASE_SYNC_IN()                                \
@@ -163,62 +107,100 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   __builtin_amdgcn_s_barrier();                        \
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_setprio(1)
+  // epilogue barrier: LDS traffic only.  __syncthreads() would add s_waitcnt vmcnt(0) = wait for the next tile's prefetch and
+  // for this tile's global stores at every pass.
+#define EPI_SYNC()                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+  __builtin_amdgcn_s_barrier();                        \
+  asm volatile("" ::: "memory")
 #define PHASE_SYNC_OUT()                               \
   __builtin_amdgcn_s_setprio(0);                       \
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_barrier();                        \
   __builtin_amdgcn_sched_barrier(0)
-#define MFMA_QUADRANT(FC, FR, CB0, RB0)                                                                              \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                   \
-    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                                 \
-      _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                               \
-        acc[(CB0) + cb][(RB0) + rb] =                                                                                \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FC[cb][ks], FR[rb][ks], acc[(CB0) + cb][(RB0) + rb], 0, 0, 0)
 
-  // ragged tiles: a wave whose 64-row / 32-column strips lie outside the tile skips those reads and MFMAs (it still issues
-  // its share of the DMA and takes every barrier)
-  const int rows_here = (MODE == 0 ? rows : min(BM2, p.NR - tr0)) - wm * 64;
-  const int cols_here = min(BN2, p.NC - tc0) - wn * 32;
-  const bool act1 = rows_here > 0 && cols_here > 0;        // C_lo x R_lo
-  const bool act2 = rows_here > 0 && cols_here > 128;      // C_hi x R_lo
-  const bool act3 = rows_here > 128 && cols_here > 128;    // C_hi x R_hi
-  const bool act4 = rows_here > 128 && cols_here > 0;      // C_lo x R_hi
+  // ---------------- first tile: descriptors + K-tile 0 ----------------
+  TileW cur;
+  DmaW dcur;
+  {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    __builtin_assume(tid >= 0 && tid < 512);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cur = tile_of(p, v_begin, nct, per_e);
+    dcur = dma_of(p, cur, ldr_b, ldc_b, wave, lane);
+    ISSUE_RL(dcur, cur, 0); ISSUE_RH(dcur, cur, 0); ISSUE_CL(dcur, cur, 0); ISSUE_CH(dcur, cur, 0);
+  }
 
-  if constexpr (SCHED == WIDE) {
-    // TWO phases of 32 MFMA per K-tile (half the barriers of the 4-phase loop; all 8 row blocks stay in registers):
-    //     phase A: read CL, RL, RH(s)   issue CL,CH(s+1)   vmcnt(8)   MFMA C_lo x R_all
-    //     phase B: read CH(s)           issue RL,RH(s+2)   vmcnt(6)   MFMA C_hi x R_all
+  bool first = true;
+  for (int v = v_begin; v < v_end; v += v_step) {
+    // Everything derived from the thread id is tile-invariant; left visible, hipcc hoists dozens of such values out of this loop,
+    // keeps them live across the K-loop and spills.  An opaque copy per tile pins them inside the iteration (~100 VALU per tile).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    __builtin_assume(tid >= 0 && tid < 512);       // give the range back: LDS offsets fold into ds_read immediates again
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;       // row half, column quarter
+
+    // ---------------- LDS read addressing ----------------
+    const int g = lane >> 4, i16 = lane & 15;
+    const int q = i16 >> 2, pp = i16 & 3;
+    const int fk = q | ((g & 1) << 2);
+    const int r_blk0 = wm * 4, c_blk0 = wn * 2;    // this wave's 16-wide blocks inside the R / C images
+    int km_r[4], km_c[2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) km_r[b] = (8 * g + q) * 256 + (((r_blk0 + b) ^ fk) << 5) + pp * 8;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) km_c[b] = (8 * g + q) * 256 + (((c_blk0 + b) ^ fk) << 5) + pp * 8;
+
+    f32x4 acc[4][8];   // [column block][row block]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (cur.red_len + BK2 - 1) / BK2;
+    // ragged tiles: a wave whose strips lie outside the tile skips those reads and MFMAs (it still issues its DMA share)
+    const int rows_here = min(BM2, p.NR - cur.tr0) - wm * 64;
+    const int cols_here = min(BN2, p.NC - cur.tc0) - wn * 32;
     const bool actA = rows_here > 0 && cols_here > 0, actAh = rows_here > 128 && cols_here > 0;
     const bool actB = rows_here > 0 && cols_here > 128, actBh = rows_here > 128 && cols_here > 128;
-    ISSUE_RL(0); ISSUE_RH(0); ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(1); ISSUE_RH(1);
-    WAIT_DMA(6);                                           // RL, RH, CL(0) landed
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
+
+    // K-tile 0 of this tile is in flight or landed (issued before the previous tile's epilogue); K-tile 1's row images now
+    ISSUE_RL(dcur, cur, 1); ISSUE_RH(dcur, cur, 1);
+    if (first) {
+      WAIT_DMA(6);                                           // RL, RH, CL(0) landed (CH(0) is checked in phase A)
+      __builtin_amdgcn_s_barrier();
+    }                                                        // later tiles: confirmed in the previous epilogue
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // row half 1 starts half a phase late
     __builtin_amdgcn_sched_barrier(0);
+    //     phase A: read CL, RL, RH(s)   issue CL,CH(s+1)   vmcnt(8)   MFMA C_lo x R_all
+    //     phase B: read CH(s)           issue RL,RH(s+2)   vmcnt(6)   MFMA C_hi x R_all
     for (int s = 0; s < nk; ++s) {
       const char* base = smem + (s & 1) * (4 * TILE_B);
       const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
       bf16x8 fc[2][2], fr[8][2];
-      // ---- phase A
       if (actA) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km(i_cl, km_c[cb], ks);
+          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_cl, km_c[cb], ks);
       }
       if (actA || actB) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km(i_rl, km_r[rb], ks);
+          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_km_raw(i_rl, km_r[rb], ks);
       }
       if (actAh || actBh) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km(i_rh, km_r[rb], ks);
+          for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = frag_km_raw(i_rh, km_r[rb], ks);
       }
-      ISSUE_CL(s + 1); ISSUE_CH(s + 1);
+      ISSUE_CL(dcur, cur, s + 1); ISSUE_CH(dcur, cur, s + 1);
       WAIT_DMA(8);                                         // CH(s) landed
       PHASE_SYNC_IN();
       if (actA) {
@@ -240,14 +222,13 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
               acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
       }
       PHASE_SYNC_OUT();
-      // ---- phase B
       if (actB) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km(i_ch, km_c[cb], ks);
+          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
       }
-      ISSUE_RL(s + 2); ISSUE_RH(s + 2);
+      ISSUE_RL(dcur, cur, s + 2); ISSUE_RH(dcur, cur, s + 2);
       WAIT_DMA(6);                                         // RL, RH, CL(s+1) landed
       PHASE_SYNC_IN();
       if (actB) {
@@ -271,183 +252,95 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
       PHASE_SYNC_OUT();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
-  } else {
-  // prologue: K-tile 0 complete; SHALLOW also the column images of K-tile 1, DEEP all of K-tile 1 except RH
-  ISSUE_RL(0); ISSUE_CL(0); ISSUE_CH(0); ISSUE_RH(0);
-  if (SCHED == DEEP) { ISSUE_RL(1); ISSUE_CL(1); ISSUE_CH(1); WAIT_DMA(10); }
-  else               { ISSUE_CL(1); ISSUE_CH(1); WAIT_DMA(4); }
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
-  __builtin_amdgcn_sched_barrier(0);
 
-  for (int s = 0; s < nk; ++s) {
-    const char* base = smem + (s & 1) * (4 * TILE_B);
-    const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-    bf16x8 fcl[2][2], fch[2][2], fr[4][2];
+    // the zero-fill DMAs of the K-tiles past the end may still be writing LDS: drain before anything reuses the slots
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- phase 1: C_lo x R_lo
-    if (act1 || act4) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fcl[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km(i_cl, km_c[cb], ks);
+    // ---------------- next tile: descriptors, K-tile 0 into the (now dead) parity-0 slots ----------------
+    const bool has_next = v + v_step < v_end;
+    TileW nxt = cur;
+    DmaW dnxt = dcur;
+    if (has_next) {
+      nxt = tile_of(p, v + v_step, nct, per_e);
+      dnxt = dma_of(p, nxt, ldr_b, ldc_b, wave, lane);
+      ISSUE_RL(dnxt, nxt, 0); ISSUE_RH(dnxt, nxt, 0); ISSUE_CL(dnxt, nxt, 0); ISSUE_CH(dnxt, nxt, 0);
     }
-    if (act1 || act2) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km(i_rl, km_r[rb], ks);
-    }
-    if (SCHED == DEEP) { ISSUE_RH(s + 1); WAIT_DMA(10); }   // CH(s) landed
-    else               { ISSUE_RL(s + 1); }
-    PHASE_SYNC_IN();
-    if (act1) { MFMA_QUADRANT(fcl, fr, 0, 0); }
-    PHASE_SYNC_OUT();
 
-    // ---- phase 2: C_hi x R_lo
-    if (act2 || act3) {
+    // ---------------- epilogue: four passes of 64 rows through an fp32 tile in the upper half of LDS ----------------
+    // pass (h, u): row blocks 4h + 2u + {0,1} of every wave -> staging row wm*32 + i*16 + (lane & 15)
+    //              = tile row h*128 + wm*64 + u*32 + i*16 + (lane & 15)
+    float* stg = (float*)(smem + STG_OFF);
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, g_e = lane_e >> 4, i16_e = lane_e & 15;
+    const int ec = (tid_e & 31) * 8;             // this thread's 8 columns inside the 256-wide tile
+    const int er = tid_e >> 5;                   // 0..15
+    const int ncol = cur.tc0 + ec;
+    typedef __attribute__((address_space(1))) char gchar;
+    gchar* Ce = (gchar*)(p.out_ptrs ? (char*)sload_b64(p.out_ptrs + cur.e) : (char*)p.single_C);
+    const int nrows = p.NR - cur.tr0;            // valid tile rows (may exceed 256)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fch[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km(i_ch, km_c[cb], ks);
-    }
-    if (SCHED == DEEP) { ISSUE_RL(s + 2); WAIT_DMA(10); }   // RH(s) landed
-    else               { ISSUE_RH(s + 1); }
-    PHASE_SYNC_IN();
-    if (act2) { MFMA_QUADRANT(fch, fr, 2, 0); }
-    PHASE_SYNC_OUT();
-
-    // ---- phase 3: C_hi x R_hi
-    if (act3 || act4) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km(i_rh, km_r[rb], ks);
-    }
-    ISSUE_CL(s + 2);
-    PHASE_SYNC_IN();
-    if (act3) { MFMA_QUADRANT(fch, fr, 2, 4); }
-    PHASE_SYNC_OUT();
-
-    // ---- phase 4: C_lo x R_hi.  After this phase's wait + barrier A every image of K-tile s+1 that phase 1 reads has landed.
-    ISSUE_CH(s + 2);
-    if (SCHED == DEEP) { WAIT_DMA(10); } else { WAIT_DMA(4); }
-    PHASE_SYNC_IN();
-    if (act4) { MFMA_QUADRANT(fcl, fr, 0, 4); }
-    PHASE_SYNC_OUT();
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
-
-  }
-
-  // the zero-fill DMAs of the K-tiles past the end may still be writing LDS: drain before the staging tile reuses it
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---------------- epilogue: two passes of 128 rows through an fp32 LDS tile ----------------
-  float* stg = (float*)smem;
-  // The tile loop makes every lane-derived epilogue address loop-invariant; hipcc would hoist ~40 of them across the K-loop and
-  // spill.  An opaque copy of the thread id pins their computation here (a handful of VALU per tile).
-  int tid_e = tid;
-  asm volatile("" : "+v"(tid_e));
-  const int lane_e = tid_e & 63, g_e = lane_e >> 4, i16_e = lane_e & 15;
-  const int ec = (tid_e & 31) * 8;             // this thread's 8 columns inside the 256-wide tile
-  const int er = tid_e >> 5;                   // 0..15
-  const int ncol = tc0 + ec;
-  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (MODE == 0 && ncol < p.NC && (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT)) {
-    const bf16* bias = (const bf16*)(p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias);
-    if (bias) {
-      bf16x8 b8 = *(const bf16x8*)(bias + ncol);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = (float)b8[j];
-    }
-  }
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    {
-      // acc[cb][rb]: rb < 4 -> row image RL, rb >= 4 -> RH; cb < 2 -> column image CL, cb >= 2 -> CH
+    for (int pass = 0; pass < 4; ++pass) {
+      const int h = pass >> 1, u = pass & 1;
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          const int m = wm * 64 + rb * 16 + i16_e;
+        for (int i = 0; i < 2; ++i) {
+          const int m = wm * 32 + i * 16 + i16_e;
           const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g_e;
-          *(f32x4*)(stg + m * CT2_LD + n) = pass == 0 ? acc[cb][rb] : acc[cb][4 + rb];
+          *(f32x4*)(stg + m * CT2_LD + n) = acc[cb][4 * h + 2 * u + i];
         }
-    }
-    __syncthreads();
-    if (ncol < p.NC) {
-      if (MODE == 0) {
-        const int rlim = min(128, rows - pass * 128);
-#pragma unroll 1
-        for (int r = er; r < rlim; r += 16) {
-          const f32x4 lo = *(const f32x4*)(stg + r * CT2_LD + ec), hi = *(const f32x4*)(stg + r * CT2_LD + ec + 4);
-          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          const int64_t o = (int64_t)(row0 + pass * 128 + r) * p.ldc + ncol;
-          bf16x8 o0;
-          if (p.epilogue == CSMOE_EPI_ACTGRAD) {
-            const bf16x8 h8 = *(const bf16x8*)((const bf16*)p.aux + o);
-            float h[8];
+      EPI_SYNC();
+      f32x4 lo[4], hi[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { h[j] = (float)h8[j]; v[j] = (float)(bf16)v[j]; }
-            act_bwd8(h, p.act);
+      for (int j = 0; j < 4; ++j) {
+        const int r = er + 16 * j;
+        lo[j] = *(const f32x4*)(stg + r * CT2_LD + ec);
+        hi[j] = *(const f32x4*)(stg + r * CT2_LD + ec + 4);
+      }
+      if (pass == 3) {
+        // next tile's K-tile 0 (issued four passes ago) must have landed before the closing barrier; taken before this
+        // pass's stores so that it does not wait for them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (ncol < p.NC) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o0[j] = (bf16)(v[j] * h[j]);
-            *(bf16x8*)((bf16*)p.C + o) = o0;
-          } else {
+        for (int j = 0; j < 4; ++j) {
+          const int r = er + 16 * j;
+          const int trow = h * 128 + (r >> 5) * 64 + u * 32 + (r & 31);
+          if (trow < nrows) {
+            const int64_t o = (int64_t)(cur.tr0 + trow) * p.ldc + ncol;
+            if (p.out_f32) {
+              typedef __attribute__((address_space(1))) f32x4 gf32x4;
+              gf32x4* dst = (gf32x4*)(Ce + o * 4);
+              f32x4 a = lo[j], b = hi[j];
+              if (p.accumulate) { a += dst[0]; b += dst[1]; }
+              dst[0] = a; dst[1] = b;
+            } else {
+              typedef __attribute__((address_space(1))) bf16x8 gbf16x8;
+              gbf16x8* dst = (gbf16x8*)(Ce + o * 2);
+              float vv[8] = {lo[j][0], lo[j][1], lo[j][2], lo[j][3], hi[j][0], hi[j][1], hi[j][2], hi[j][3]};
+              if (p.accumulate) {
+                const bf16x8 old = *dst;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { o0[j] = (bf16)(v[j] + bv[j]); v[j] = (float)o0[j]; }
-            *(bf16x8*)((bf16*)p.C + o) = o0;
-            if (p.epilogue == CSMOE_EPI_BIAS_ACT && p.C2) {
-              act_fwd8(v, p.act);
-              bf16x8 o1;
+                for (int t = 0; t < 8; ++t) vv[t] += (float)old[t];
+              }
+              bf16x8 o8;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) o1[j] = (bf16)v[j];
-              *(bf16x8*)((bf16*)p.C2 + o) = o1;
+              for (int t = 0; t < 8; ++t) o8[t] = (bf16)vv[t];
+              *dst = o8;
             }
-          }
-        }
-      } else {
-        char* Ce = (char*)(p.out_ptrs ? p.out_ptrs[e] : p.single_C);
-        const int rlim = min(128, p.NR - tr0 - pass * 128);
-#pragma unroll 1
-        for (int r = er; r < rlim; r += 16) {
-          f32x4 lo = *(const f32x4*)(stg + r * CT2_LD + ec), hi = *(const f32x4*)(stg + r * CT2_LD + ec + 4);
-          const int64_t o = (int64_t)(tr0 + pass * 128 + r) * p.ldc + ncol;
-          if (p.out_f32) {
-            f32x4* dst = (f32x4*)(Ce + o * 4);
-            if (p.accumulate) { lo += dst[0]; hi += dst[1]; }
-            dst[0] = lo; dst[1] = hi;
-          } else {
-            bf16x8* dst = (bf16x8*)(Ce + o * 2);
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (p.accumulate) {
-              const bf16x8 old = *dst;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] += (float)old[j];
-            }
-            bf16x8 o8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o8[j] = (bf16)v[j];
-            *dst = o8;
           }
         }
       }
+      EPI_SYNC();
     }
-    __syncthreads();
-  }
+    cur = nxt;
+    dcur = dnxt;
+    first = false;
   }   // persistent tile loop
-}
-
-int sched_pref() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CSMOE_GEMM_SCHED");
-    v = e ? atoi(e) : WIDE;
-  }
-  return v;
 }
 
 int persistent_grid(int64_t tiles_upper) {
@@ -463,11 +356,10 @@ int persistent_grid(int64_t tiles_upper) {
   return (int)std::min<int64_t>(tiles_upper, ncu);
 }
 
-template <typename K>
-int set_lds2(K kern) {
+int set_lds2() {
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gg8w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     if (e != hipSuccess) { csmoe_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return CSMOE_ERR_LAUNCH; }
     done = true;
   }
@@ -486,13 +378,8 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
   if (grid <= 0) return CSMOE_OK;
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_wgrad: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;
-  if (sched_pref() == WIDE) {
-    if ((rc = set_lds2(gg8_kernel<KM, KM, 1, WIDE>))) return rc;
-    hipLaunchKernelGGL((gg8_kernel<KM, KM, 1, WIDE>), dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
-  } else {
-    if ((rc = set_lds2(gg8_kernel<KM, KM, 1, DEEP>))) return rc;
-    hipLaunchKernelGGL((gg8_kernel<KM, KM, 1, DEEP>), dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
-  }
+  if ((rc = set_lds2())) return rc;
+  hipLaunchKernelGGL(gg8w_kernel, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
   CSMOE_CHECK_LAUNCH("grouped_wgrad(bf16 v2)");
   return CSMOE_OK;
 }

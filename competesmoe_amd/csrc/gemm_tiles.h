@@ -110,6 +110,28 @@ __device__ __forceinline__ bf16x8 frag_km(const char* tile, int addr_cb, int s) 
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// Same fragment by inline asm, for the hand-scheduled v2 loops.  hipcc's waitcnt pass cannot tell which LDS bytes a pending
+// LDS-DMA (buffer_load ... lds) will write and puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 builtin: that
+// drained the whole prefetch queue twice per K-tile in every kernel with a K-major image (profiles/r01).  The asm form is
+// invisible to that pass; the CALLER owns the ordering: the counted vmcnt + s_barrier before the slot is read, and
+// `s_waitcnt lgkmcnt(0)` before the first use of the result (PHASE_SYNC_IN does both).
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ bf16x8 frag_km_raw(const char* tile, int addr_cb, int s) {
+  const unsigned a = lds_addr(tile) + (unsigned)addr_cb;
+  i32x2 lo, hi;
+  if (s == 0) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a) : "memory");
+  } else {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(lo) : "v"(a) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(hi) : "v"(a) : "memory");
+  }
+  i32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // ---- fast GELU for the bf16 epilogues -------------------------------------------------------------------------------------
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below half a bf16 ulp), one v_exp + one v_rcp: the OCML erff costs
 // ~50 instructions and made the bias+GELU epilogue ~30 % of a K=4096 tile (profiles/r01).  The fp32 path (gemm_generic.hip)
