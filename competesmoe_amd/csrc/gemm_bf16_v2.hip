@@ -35,7 +35,6 @@ using namespace ggt;
 namespace {
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
-constexpr int BUF_B = 4 * TILE_B;            // one K-tile buffer: R0, R1, C0, C1
 constexpr int CT2_LD = BN2 + 4;              // fp32 epilogue staging row stride (floats); 128 rows per pass
 constexpr int LDS2_BYTES = 128 * CT2_LD * 4; // 133,120 B  (>= 2 * BUF_B = 131,072 B)
 

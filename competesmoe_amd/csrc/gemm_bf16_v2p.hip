@@ -1,20 +1,30 @@
 // Persistent weight-gradient GEMM for gfx950: dW[e] = A[rows of e]^T @ B[rows of e]  (bf16 operands, fp32 accumulate).
-// Same 256x256 tile / 8 waves / K-tile 64 / WIDE two-phase schedule as the row-space kernel in gemm_bf16_v2.hip (see its
+// Same 256x256 tile / 8 waves / K-tile 64 / two-phase staggered loop as the row-space kernel in gemm_bf16_v2.hip (see its
 // header for the image kinds, the half-phase stagger of waves 4-7 and the counted-vmcnt rules); what differs is the outer
-// structure.  The headline launch is 44k tiles of only ~16 K-tiles each, so what happens BETWEEN tiles matters as much as
-// the K-loop:
+// structure and the placement of the DMA issue.  The headline launch is 44k tiles of only ~16 K-tiles each, so what happens
+// BETWEEN tiles matters as much as the K-loop (s_memtime stamps of this kernel, -DCSMOE_STAMPS, profiles/r01/wgrad_stamps.txt:
+// per tile ~48k cycles K-loop = 3.0k per K-tile of which 2,048 are MFMA, ~8k epilogue, ~1.7k everything else):
 //   * one workgroup per CU walks its XCD's contiguous chunk of the tile order (no re-dispatch of a 512-thread / 130 KiB
 //     workgroup per tile);
-//   * the epilogue stages the accumulators through the UPPER 64 KiB of LDS only (4 passes of 64 rows), so K-tile 0 of the NEXT
-//     tile (4 images, the parity-0 slots in the lower 64 KiB) is fetched by LDS-DMA while this tile is converted and stored:
-//     the first-byte latency of a tile no longer sits between two K-loops;
-//   * the wait for that prefetch is taken in the last pass, BEFORE its global stores are issued (vmcnt retires in order on
-//     gfx9: waiting later would also wait for the stores), and K-tile 1's row images are issued right after the pass's closing
-//     barrier, when the staging area (= the parity-1 slots) is dead.
+//   * the epilogue stages through the UPPER 64 KiB of LDS only, so K-tile 0 of the NEXT tile (4 images, the parity-0 slots in
+//     the lower 64 KiB) is fetched by LDS-DMA while this tile is converted and stored; the wait for that prefetch is taken in
+//     the last pass, BEFORE its global stores are issued (vmcnt retires in order on gfx9: waiting later would also wait for
+//     the stores);
+//   * bf16 output without accumulate (the training path) rounds in registers and stages bf16: two passes of 128 rows with
+//     ds_write_b64, half the LDS write bytes and half the barriers of the fp32 staging (4 passes of 64 rows) that fp32 output /
+//     accumulate keep (~8.1k vs ~10.1k cycles per tile);
+//   * barriers of the epilogue wait for LDS only (__syncthreads() adds s_waitcnt vmcnt(0) = the prefetch and the stores), the
+//     offsets / output-pointer tables are read with scalar loads (hipcc's vector loads cost a vmcnt(0) per use).
+// Tried and dropped (same box A/B, tools/gemm_bench.py): storing the accumulators straight from registers (32-byte row
+// segments per store: -6 %); a software-pipelined loop with single-buffered just-in-time fragments and ONE barrier per K-tile
+// (2.64k cycles per K-tile with cache-resident operands, but 3.2k with real ones: its prefetch lead is one K-tile where the
+// staggered loop has 1.5); the split DMA schedule below is +1..2 % here and -3..6 % in the long-K row-space launches, which
+// keep all DMA issue in the read sections.
 // Both operands are K-major ([rows, features]): KM images read with ds_read_b64_tr_b16.
 #include "gemm_tiles.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 
 using namespace ggt;
 
@@ -24,6 +34,18 @@ constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int CT2_LD = BN2 + 4;                       // fp32 staging row stride (floats)
 constexpr int STG_OFF = 4 * TILE_B;                   // staging tile = upper half (the parity-1 slots)
 constexpr int LDS2_BYTES = STG_OFF + 64 * CT2_LD * 4; // 132,096 B  (>= 8 * TILE_B = 131,072 B)
+
+// Diagnostic build (-DCSMOE_STAMPS): workgroup 0 / thread 0 records s_memtime at the marked points of its first 24 tiles
+// into the buffer passed in FastArgs::aux; gg8_wgrad prints the per-section cycle counts (tools/gemm_bench.py --which tn1).
+#ifdef CSMOE_STAMPS
+#define STAMP(k)                                                                                             \
+  do {                                                                                                       \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && tile_i < 24)                                                  \
+      ((unsigned long long*)p.aux)[tile_i * 16 + (k)] = __builtin_readcyclecounter();                        \
+  } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 struct TileW { int e, row0, red_len, tr0, tc0; };     // wave-uniform
 struct DmaW {
@@ -62,9 +84,14 @@ __device__ __forceinline__ TileW tile_of(const FastArgs& p, int v, int nct, int 
   return t;
 }
 
-__device__ __forceinline__ DmaW dma_of(const FastArgs& p, const TileW& t, unsigned ldr_b, unsigned ldc_b, int wave, int lane) {
+__device__ __forceinline__ DmaW dma_of(const FastArgs& p, const TileW& t_in, unsigned ldr_b, unsigned ldc_b, int wave, int lane) {
   DmaW d;
   int ax[2];
+#ifdef CSMOE_FAKE_LOCAL
+  TileW t = t_in; t.row0 = 0; t.tr0 = 0; t.tc0 = 0;      // timing experiment: every tile reads the same (cache-resident) panels
+#else
+  const TileW& t = t_in;
+#endif
   d.rs_r = make_rsrc((const char*)p.R + (int64_t)t.row0 * ldr_b, (unsigned)t.red_len * ldr_b);
   d.rs_c = make_rsrc((const char*)p.Cflat + (int64_t)t.row0 * ldc_b, (unsigned)t.red_len * ldc_b);
   dma_setup<KM, 2>(d.vb_rl, ax, ldr_b, t.tr0, p.NR, 7, 0, 0, wave, lane);
@@ -134,7 +161,11 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
   }
 
   bool first = true;
+  int tile_i = -1;
   for (int v = v_begin; v < v_end; v += v_step) {
+    ++tile_i;
+    (void)tile_i;
+    STAMP(0);
     // Everything derived from the thread id is tile-invariant; left visible, hipcc hoists dozens of such values out of this loop,
     // keeps them live across the K-loop and spills.  An opaque copy per tile pins them inside the iteration (~100 VALU per tile).
     int tid = threadIdx.x;
@@ -168,16 +199,31 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
     const bool actA = rows_here > 0 && cols_here > 0, actAh = rows_here > 128 && cols_here > 0;
     const bool actB = rows_here > 0 && cols_here > 128, actBh = rows_here > 128 && cols_here > 128;
 
-    // K-tile 0 of this tile is in flight or landed (issued before the previous tile's epilogue); K-tile 1's row images now
-    ISSUE_RL(dcur, cur, 1); ISSUE_RH(dcur, cur, 1);
+    // Split DMA schedule: the 8 pieces a wave issues per K-tile are spread so that no segment carries both the 40 fragment
+    // reads of phase A and DMA issue (an LDS-DMA piece costs its wave 100-185 cycles next to ds_reads, ~60 between MFMAs):
+    //     LA(s): read CL, RL, RH(s)               vmcnt(6): CH(s) landed
+    //     MA(s): 32 MFMA + CH(s+1) (2 pieces, after the 8th and 24th MFMA)
+    //     LB(s): read CH(s)   issue RL, RH(s+2)   vmcnt(6): RL, RH, CL(s+1) landed
+    //     MB(s): 32 MFMA + CL(s+2) (2 pieces)
+    // Issue order per wave: ... RL,RH(s+2) | CL(s+2) | CH(s+2) | RL,RH(s+3) ...; every slot is refilled only after the
+    // barrier that follows the staggered half's read of it.
+#define PIECE_CL(tile, j) dma_piece<KM, 2>(dcur.rs_c, SLOT(1, tile), dcur.vb_cl[j], 0, j, (tile) * BK2, cur.red_len, ldc_b, wave)
+#define PIECE_CH(tile, j) dma_piece<KM, 2>(dcur.rs_c, SLOT(2, tile), dcur.vb_ch[j], 0, j, (tile) * BK2, cur.red_len, ldc_b, wave)
+#define MFMA_HALF(COND, CB0, RB0, KS)                                                                              \
+    if (COND) {                                                                                                      \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                               \
+        _Pragma("unroll") for (int rb = (RB0); rb < (RB0) + 4; ++rb)                                                 \
+          acc[(CB0) + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][KS], fr[rb][KS], acc[(CB0) + cb][rb], 0, 0, 0); \
+    }
+#define PINNED(X) __builtin_amdgcn_sched_barrier(0); X; __builtin_amdgcn_sched_barrier(0)
+    ISSUE_RL(dcur, cur, 1); ISSUE_RH(dcur, cur, 1); ISSUE_CL(dcur, cur, 1);
     if (first) {
-      WAIT_DMA(6);                                           // RL, RH, CL(0) landed (CH(0) is checked in phase A)
+      WAIT_DMA(8);                                           // RL, RH, CL(0) landed (CH(0) is checked in LA(0))
       __builtin_amdgcn_s_barrier();
-    }                                                        // later tiles: confirmed in the previous epilogue
+    }                                                        // later tiles: K-tile 0 confirmed in the previous epilogue
     if (wm == 1) __builtin_amdgcn_s_barrier();               // row half 1 starts half a phase late
     __builtin_amdgcn_sched_barrier(0);
-    //     phase A: read CL, RL, RH(s)   issue CL,CH(s+1)   vmcnt(8)   MFMA C_lo x R_all
-    //     phase B: read CH(s)           issue RL,RH(s+2)   vmcnt(6)   MFMA C_hi x R_all
+    STAMP(1);
     for (int s = 0; s < nk; ++s) {
       const char* base = smem + (s & 1) * (4 * TILE_B);
       const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
@@ -200,27 +246,14 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = frag_km_raw(i_rh, km_r[rb], ks);
       }
-      ISSUE_CL(dcur, cur, s + 1); ISSUE_CH(dcur, cur, s + 1);
-      WAIT_DMA(8);                                         // CH(s) landed
+      if (s > 0 || first) WAIT_DMA(6);                     // CH(s) landed
       PHASE_SYNC_IN();
-      if (actA) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
-      if (actAh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 4; rb < 8; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
+      MFMA_HALF(actA, 0, 0, 0)
+      PINNED(PIECE_CH(s + 1, 0));
+      MFMA_HALF(actA, 0, 0, 1)
+      MFMA_HALF(actAh, 0, 4, 0)
+      PINNED(PIECE_CH(s + 1, 1));
+      MFMA_HALF(actAh, 0, 4, 1)
       PHASE_SYNC_OUT();
       if (actB) {
 #pragma unroll
@@ -231,33 +264,23 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
       ISSUE_RL(dcur, cur, s + 2); ISSUE_RH(dcur, cur, s + 2);
       WAIT_DMA(6);                                         // RL, RH, CL(s+1) landed
       PHASE_SYNC_IN();
-      if (actB) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
-      }
-      if (actBh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 4; rb < 8; ++rb)
-              acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
-      }
+      MFMA_HALF(actB, 2, 0, 0)
+      PINNED(PIECE_CL(s + 2, 0));
+      MFMA_HALF(actB, 2, 0, 1)
+      MFMA_HALF(actBh, 2, 4, 0)
+      PINNED(PIECE_CL(s + 2, 1));
+      MFMA_HALF(actBh, 2, 4, 1)
       PHASE_SYNC_OUT();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
+    STAMP(2);
 
     // the zero-fill DMAs of the K-tiles past the end may still be writing LDS: drain before anything reuses the slots
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
+    STAMP(3);
     // ---------------- next tile: descriptors, K-tile 0 into the (now dead) parity-0 slots ----------------
     const bool has_next = v + v_step < v_end;
     TileW nxt = cur;
@@ -268,6 +291,7 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
       ISSUE_RL(dnxt, nxt, 0); ISSUE_RH(dnxt, nxt, 0); ISSUE_CL(dnxt, nxt, 0); ISSUE_CH(dnxt, nxt, 0);
     }
 
+    STAMP(4);
     // ---------------- epilogue: four passes of 64 rows through an fp32 tile in the upper half of LDS ----------------
     // pass (h, u): row blocks 4h + 2u + {0,1} of every wave -> staging row wm*32 + i*16 + (lane & 15)
     //              = tile row h*128 + wm*64 + u*32 + i*16 + (lane & 15)
@@ -281,6 +305,48 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
     typedef __attribute__((address_space(1))) char gchar;
     gchar* Ce = (gchar*)(p.out_ptrs ? (char*)sload_b64(p.out_ptrs + cur.e) : (char*)p.single_C);
     const int nrows = p.NR - cur.tr0;            // valid tile rows (may exceed 256)
+    if (!p.out_f32 && !p.accumulate) {
+      // bf16 output, no read-modify-write: round in registers and stage bf16 -- two passes of 128 rows (row stride 520 B:
+      // the 8-byte ds_write_b64 of 16 consecutive rows fall on 16 different bank pairs), half the LDS write bytes and half
+      // the barriers of the fp32 path below
+      char* stg_b = smem + STG_OFF;
+      constexpr int SB = BN2 * 2 + 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) {
+            const int m = wm * 64 + rb * 16 + i16_e;
+            const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g_e;
+            const f32x4 a = acc[cb][4 * h + rb];
+            bf16x4 o4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o4[t] = (bf16)a[t];
+            *(bf16x4*)(stg_b + m * SB + n * 2) = o4;
+          }
+        EPI_SYNC();
+        if (h == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's K-tile 0 landed; before this pass's stores
+#pragma unroll
+        for (int jj = 0; jj < 8; jj += 4) {
+          bf16x8 row[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) row[j] = *(const bf16x8*)(stg_b + (er + 16 * (jj + j)) * SB + ec * 2);
+          if (ncol < p.NC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int trow = h * 128 + er + 16 * (jj + j);
+              if (trow < nrows) {
+                typedef __attribute__((address_space(1))) bf16x8 gbf16x8;
+                *(gbf16x8*)(Ce + ((int64_t)(cur.tr0 + trow) * p.ldc + ncol) * 2) = row[j];
+              }
+            }
+          }
+        }
+        EPI_SYNC();
+        STAMP(5 + h);
+      }
+    } else
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int h = pass >> 1, u = pass & 1;
@@ -336,6 +402,7 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
         }
       }
       EPI_SYNC();
+      STAMP(5 + pass);
     }
     cur = nxt;
     dcur = dnxt;
@@ -379,7 +446,28 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_wgrad: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;
   if ((rc = set_lds2())) return rc;
+#ifdef CSMOE_STAMPS
+  static unsigned long long* dbg = nullptr;
+  if (!dbg) (void)hipMalloc(&dbg, 24 * 16 * 8);
+  (void)hipMemsetAsync(dbg, 0, 24 * 16 * 8, st);
+  p.aux = dbg;
+#endif
   hipLaunchKernelGGL(gg8w_kernel, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
+#ifdef CSMOE_STAMPS
+  {
+    static unsigned long long h[24 * 16];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    const char* nm[9] = {"top->loop", "K-loop", "drain", "next-setup+K0", "pass0", "pass1", "pass2", "pass3", "to-next-top"};
+    for (int t = 2; t < 24 && h[t * 16]; t += 7) {
+      fprintf(stderr, "[stamps] tile %d:", t);
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%lld", nm[k], (long long)(h[t * 16 + k + 1] - h[t * 16 + k]));
+      if (h[(t + 1) * 16]) fprintf(stderr, " %s=%lld total=%lld", nm[8], (long long)(h[(t + 1) * 16] - h[t * 16 + 8]),
+                                   (long long)(h[(t + 1) * 16] - h[t * 16]));
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   CSMOE_CHECK_LAUNCH("grouped_wgrad(bf16 v2)");
   return CSMOE_OK;
 }
