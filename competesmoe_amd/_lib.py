@@ -35,7 +35,7 @@ SIGNATURES = {
     "csmoe_dispatch_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "csmoe_dispatch_tokens": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "csmoe_dispatch_rows_bwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p]),
-    "csmoe_combine": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "csmoe_combine": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "csmoe_combine_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "csmoe_grouped_gemm": (_i, [_p, _l, _p, _i, _l, _p, _p, _i, _i, _i, _i, _p, _p, _p, _l, _i, _i, _i, _i, _p]),
     "csmoe_dense_gemm": (_i, [_p, _l, _p, _i, _l, _p, _i, _i, _i, _p, _p, _p, _l, _i, _i, _i, _i, _p]),
@@ -45,6 +45,9 @@ SIGNATURES = {
     "csmoe_dense_colsum": (_i, [_p, _l, _i, _i, _p, _i, _i, _p]),
     "csmoe_softplus_mean": (_i, [_p, _p, _i, _i, _i, _p]),
     "csmoe_softplus_mean_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "csmoe_layernorm_gate": (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
+    "csmoe_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "csmoe_layernorm_bwd_blocks": (_i, [_i]),
 }
 
 

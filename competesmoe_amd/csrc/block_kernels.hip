@@ -1,0 +1,344 @@
+// The MoE half of a pre-LN transformer block around the layer:   out = x + MoE(LayerNorm(x))
+//   LLaVA:    SiglipEncoderMoELayer.forward   moe_model/model/multimodal_encoder/siglip_smoe.py:141-157
+//   pretrain: RelativeMoeTransformerEncoderLayer.forward (preln)   moe_pretrain_model/layers/transformer/relative_moe_transformer.py:153-161
+// Kernels here: LayerNorm forward, optionally fused with the router's gate projection (the normalised rows are still in LDS
+// when the gate logits are computed, so the gate does not re-read them from HBM), and LayerNorm backward with the residual
+// gradient added in the same pass.  The residual add of the forward is an epilogue of the combine kernel (moe_kernels.hip).
+// All three are HBM-bound row passes: one wave per row, 16-byte accesses, statistics in fp32 as torch does.
+#include "common.h"
+
+namespace {
+
+constexpr int CPL_MAX = 16;   // 16-byte chunks per lane per row: D <= 16 * 64 * (16 / sizeof(T)) = 8192 (bf16) / 4096 (fp32)
+constexpr int LN_ROWS = 16;   // rows per workgroup of the forward (= one MFMA column block of the fused gate)
+
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16> {
+  static constexpr int N = 8;
+  typedef bf16x8 V;
+  static __device__ __forceinline__ void unpack(const V& v, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+  }
+  static __device__ __forceinline__ V pack(const float (&f)[8]) {
+    V v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)f[j];
+    return v;
+  }
+};
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  typedef f32x4 V;
+  static __device__ __forceinline__ void unpack(const V& v, float (&f)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = v[j];
+  }
+  static __device__ __forceinline__ V pack(const float (&f)[4]) { return V{f[0], f[1], f[2], f[3]}; }
+};
+
+// ------------------------------------------------------------------------------------------------------------ forward
+// grid = ceil(T / 16), block = 256 (4 waves, 4 rows each).  FUSE (bf16 only, E <= 64, D % 64 == 0): the 16 normalised rows
+// stay in LDS (16 x D bf16, 16-byte chunk c of row r at c ^ (r & 7)) and the four waves split K of the
+// [E x D] x [D x 16] gate product (v_mfma_f32_16x16x32_bf16, experts on the A side read straight from global / L2), partial
+// sums meet in LDS.
+template <typename T, bool FUSE>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                     const T* __restrict__ beta, float eps, T* __restrict__ xn,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, int Tn, int D,
+                                                     const T* __restrict__ wg, T* __restrict__ logits, int E) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef typename Chunk<T>::V V;
+  constexpr int N = Chunk<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D / N;                          // chunks per row
+  const int row0 = blockIdx.x * LN_ROWS;
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 4 + j;
+    const int R = row0 + r;
+    const bool live_row = R < Tn;
+    V v[CPL_MAX];
+    float s = 0.f;
+    if (live_row) {
+#pragma unroll
+      for (int c = 0; c < CPL_MAX; ++c) {
+        const int ci = c * 64 + lane;
+        if (ci < nch) {
+          v[c] = *(const V*)(x + (int64_t)R * D + (int64_t)ci * N);
+          float f[N];
+          Chunk<T>::unpack(v[c], f);
+#pragma unroll
+          for (int e = 0; e < N; ++e) s += f[e];
+        }
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    if (live_row) {
+#pragma unroll
+      for (int c = 0; c < CPL_MAX; ++c) {
+        const int ci = c * 64 + lane;
+        if (ci < nch) {
+          float f[N];
+          Chunk<T>::unpack(v[c], f);
+#pragma unroll
+          for (int e = 0; e < N; ++e) { const float d = f[e] - mean; q += d * d; }
+        }
+      }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (live_row && lane == 0) { mean_out[R] = mean; rstd_out[R] = rstd; }
+#pragma unroll
+    for (int c = 0; c < CPL_MAX; ++c) {
+      const int ci = c * 64 + lane;
+      if (ci < nch) {
+        V o;
+        if (live_row) {
+          float f[N], gm[N], bt[N];
+          Chunk<T>::unpack(v[c], f);
+          if (gamma) Chunk<T>::unpack(*(const V*)(gamma + (int64_t)ci * N), gm);
+          if (beta) Chunk<T>::unpack(*(const V*)(beta + (int64_t)ci * N), bt);
+#pragma unroll
+          for (int e = 0; e < N; ++e) f[e] = (f[e] - mean) * rstd * (gamma ? gm[e] : 1.f) + (beta ? bt[e] : 0.f);
+          o = Chunk<T>::pack(f);
+          *(V*)(xn + (int64_t)R * D + (int64_t)ci * N) = o;
+        } else {
+          float z[N];
+#pragma unroll
+          for (int e = 0; e < N; ++e) z[e] = 0.f;
+          o = Chunk<T>::pack(z);
+        }
+        if constexpr (FUSE) *(V*)(lds + (int64_t)r * D * 2 + ((ci ^ (r & 7)) << 4)) = o;
+      }
+    }
+  }
+  if constexpr (FUSE) {
+    __syncthreads();
+    const int i16 = lane & 15, g = lane >> 4;
+    const int neb = (E + 15) >> 4;                // expert blocks of 16 (<= 4)
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* xrow = lds + (int64_t)i16 * D * 2;
+    const int nks = D >> 5;
+    for (int ks = wave; ks < nks; ks += 4) {
+      const bf16x8 fb = *(const bf16x8*)(xrow + (((ks * 4 + g) ^ (i16 & 7)) << 4));       // tokens: B operand
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (b < neb) {
+          const int e = b * 16 + i16;
+          bf16x8 fa;
+          if (e < E) fa = *(const bf16x8*)((const bf16*)wg + (int64_t)e * D + ks * 32 + g * 8);   // experts: A operand
+          else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) fa[t] = (bf16)0.f;
+          }
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[b], 0, 0, 0);
+        }
+      }
+    }
+    // D/C layout: column (lane & 15) = token row, rows 4 * (lane >> 4) + reg = expert inside the block
+    float* part = (float*)(lds + (int64_t)LN_ROWS * D * 2);        // [4 waves][64 experts][16 rows]
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b < neb)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) part[(wave * 64 + b * 16 + 4 * g + reg) * 16 + i16] = acc[b][reg];
+    __syncthreads();
+    for (int o = threadIdx.x; o < LN_ROWS * E; o += 256) {
+      const int r = o / E, e = o - r * E;
+      if (row0 + r < Tn) {
+        const float sum = (part[(0 * 64 + e) * 16 + r] + part[(1 * 64 + e) * 16 + r]) +
+                          (part[(2 * 64 + e) * 16 + r] + part[(3 * 64 + e) * 16 + r]);
+        DT<T>::st(logits + (int64_t)(row0 + r) * E + e, sum);
+      }
+    }
+  }
+}
+
+// gradient of xn: one stream, or the x.dtype sum of two (autograd would add the expert-path and gate-path gradients first)
+template <typename T>
+__device__ __forceinline__ typename Chunk<T>::V load_grad(const T* a, const T* b, int64_t off) {
+  typedef typename Chunk<T>::V V;
+  constexpr int N = Chunk<T>::N;
+  V va = *(const V*)(a + off);
+  if (b) {
+    float fa[N], fb[N];
+    Chunk<T>::unpack(va, fa);
+    Chunk<T>::unpack(*(const V*)(b + off), fb);
+#pragma unroll
+    for (int e = 0; e < N; ++e) fa[e] += fb[e];
+    va = Chunk<T>::pack(fa);
+  }
+  return va;
+}
+
+// ----------------------------------------------------------------------------------------------------------- backward
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ add],  g = dxn * gamma,  xhat = (x - mean) * rstd
+// Persistent grid; wave w of workgroup b walks rows (it * gridDim + b) * 4 + w.  A lane always owns the same columns, so the
+// dgamma / dbeta column sums accumulate in registers over all rows of the wave; the four waves meet in LDS and every
+// workgroup writes ONE partial row [2][D] (fp32) that a column-sum launch reduces (deterministic, no atomics).
+template <typename T, int CPL, bool KEEP>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dxn, const T* __restrict__ dxn2, const T* __restrict__ x,
+                                                     const T* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, const T* __restrict__ add,
+                                                     T* __restrict__ dx, float* __restrict__ partial, int Tn, int D) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef typename Chunk<T>::V V;
+  constexpr int N = Chunk<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D / N;
+  float dg[CPL][N], db[CPL][N];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+#pragma unroll
+    for (int e = 0; e < N; ++e) { dg[c][e] = 0.f; db[c][e] = 0.f; }
+  const float invD = 1.f / (float)D;
+  for (int R = blockIdx.x * 4 + wave; R < Tn; R += gridDim.x * 4) {
+    const float mean = mean_in[R], rstd = rstd_in[R];
+    V vx[KEEP ? CPL : 1], vg[KEEP ? CPL : 1];      // KEEP: the row stays in registers for the second sweep, else it is re-read (L2)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int ci = c * 64 + lane;
+      if (ci < nch) {
+        const V ax = *(const V*)(x + (int64_t)R * D + (int64_t)ci * N);
+        const V ag = load_grad<T>(dxn, dxn2, (int64_t)R * D + (int64_t)ci * N);
+        if (KEEP) { vx[c] = ax; vg[c] = ag; }
+        float fx[N], fg[N], gm[N];
+        Chunk<T>::unpack(ax, fx);
+        Chunk<T>::unpack(ag, fg);
+        if (gamma) Chunk<T>::unpack(*(const V*)(gamma + (int64_t)ci * N), gm);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float xh = (fx[e] - mean) * rstd;
+          const float g = fg[e] * (gamma ? gm[e] : 1.f);
+          s1 += g;
+          s2 += g * xh;
+          dg[c][e] += fg[e] * xh;
+          db[c][e] += fg[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int ci = c * 64 + lane;
+      if (ci < nch) {
+        const V ax = KEEP ? vx[c] : *(const V*)(x + (int64_t)R * D + (int64_t)ci * N);
+        const V ag = KEEP ? vg[c] : load_grad<T>(dxn, dxn2, (int64_t)R * D + (int64_t)ci * N);
+        float fx[N], fg[N], gm[N], fa[N];
+        Chunk<T>::unpack(ax, fx);
+        Chunk<T>::unpack(ag, fg);
+        if (gamma) Chunk<T>::unpack(*(const V*)(gamma + (int64_t)ci * N), gm);
+        if (add) Chunk<T>::unpack(*(const V*)(add + (int64_t)R * D + (int64_t)ci * N), fa);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float xh = (fx[e] - mean) * rstd;
+          float r = rstd * (fg[e] * (gamma ? gm[e] : 1.f) - s1 - xh * s2);
+          if (add) r = DT<T>::rnd(r) + fa[e];          // the reference adds two x.dtype tensors: round, then add
+          fx[e] = r;
+        }
+        *(V*)(dx + (int64_t)R * D + (int64_t)ci * N) = Chunk<T>::pack(fx);
+      }
+    }
+  }
+  // four waves -> one partial row per workgroup
+  float* red = (float*)lds;                        // [4][2][D]
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ci = c * 64 + lane;
+    if (ci < nch) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        red[(wave * 2 + 0) * D + ci * N + e] = dg[c][e];
+        red[(wave * 2 + 1) * D + ci * N + e] = db[c][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * D; o += 256) {
+    const int which = o / D, col = o - which * D;
+    const float sum = (red[(0 * 2 + which) * D + col] + red[(1 * 2 + which) * D + col]) +
+                      (red[(2 * 2 + which) * D + col] + red[(3 * 2 + which) * D + col]);
+    partial[(int64_t)blockIdx.x * 2 * D + o] = sum;
+  }
+}
+
+template <typename K>
+int raise_lds(K kern, int bytes, const char* what) {
+  if (bytes > 160 * 1024) { csmoe_set_error("%s: %d B of LDS needed, 160 KiB available", what, bytes); return CSMOE_ERR_UNSUPPORTED; }
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { csmoe_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return CSMOE_ERR_LAUNCH; }
+  return CSMOE_OK;
+}
+
+}  // namespace
+
+int k_layernorm_max_d(int dtype) { (void)dtype; return 4096; }   // the backward keeps its column sums in registers
+
+// fused gate possible? (bf16, E <= 64, D % 32 == 0, 16 rows of D bf16 + the partial sums fit in LDS, 16-byte aligned rows)
+bool k_layernorm_can_fuse(int dtype, int D, int E) {
+  return dtype == CSMOE_BF16 && E > 0 && E <= 64 && D % 64 == 0 && LN_ROWS * D * 2 + 4 * 64 * 16 * 4 <= 160 * 1024;
+}
+
+int k_layernorm_fwd(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd, int T,
+                    int D, int dtype, const void* wg, void* logits, int E, hipStream_t st) {
+  dim3 grid((T + LN_ROWS - 1) / LN_ROWS), block(256);
+  const bool fuse = wg != nullptr;
+  int rc;
+  if (dtype == CSMOE_BF16) {
+    if (fuse) {
+      const int bytes = LN_ROWS * D * 2 + 4 * 64 * 16 * 4;
+      if ((rc = raise_lds(ln_fwd_kernel<bf16, true>, bytes, "layernorm_gate"))) return rc;
+      hipLaunchKernelGGL((ln_fwd_kernel<bf16, true>), grid, block, bytes, st, (const bf16*)x, (const bf16*)gamma, (const bf16*)beta,
+                         eps, (bf16*)xn, mean, rstd, T, D, (const bf16*)wg, (bf16*)logits, E);
+    } else {
+      hipLaunchKernelGGL((ln_fwd_kernel<bf16, false>), grid, block, 0, st, (const bf16*)x, (const bf16*)gamma, (const bf16*)beta,
+                         eps, (bf16*)xn, mean, rstd, T, D, (const bf16*)nullptr, (bf16*)nullptr, 0);
+    }
+  } else {
+    hipLaunchKernelGGL((ln_fwd_kernel<float, false>), grid, block, 0, st, (const float*)x, (const float*)gamma, (const float*)beta,
+                       eps, (float*)xn, mean, rstd, T, D, (const float*)nullptr, (float*)nullptr, 0);
+  }
+  CSMOE_CHECK_LAUNCH("layernorm_gate");
+  return CSMOE_OK;
+}
+
+int k_layernorm_bwd_blocks(int T) {
+  int nb = (T + 3) / 4;
+  return nb < 512 ? (nb < 1 ? 1 : nb) : 512;
+}
+
+template <typename T, int CPL, bool KEEP>
+int launch_ln_bwd(const void* dxn, const void* dxn2, const void* x, const void* gamma, const float* mean, const float* rstd, const void* add,
+                  void* dx, float* partial, int Tn, int D, hipStream_t st) {
+  dim3 grid(k_layernorm_bwd_blocks(Tn)), block(256);
+  const int bytes = 4 * 2 * D * 4;
+  int rc;
+  if ((rc = raise_lds(ln_bwd_kernel<T, CPL, KEEP>, bytes, "layernorm_bwd"))) return rc;
+  hipLaunchKernelGGL((ln_bwd_kernel<T, CPL, KEEP>), grid, block, bytes, st, (const T*)dxn, (const T*)dxn2, (const T*)x, (const T*)gamma, mean, rstd,
+                     (const T*)add, (T*)dx, partial, Tn, D);
+  return CSMOE_OK;
+}
+
+int k_layernorm_bwd(const void* dxn, const void* dxn2, const void* x, const void* gamma, const float* mean, const float* rstd, const void* add,
+                    void* dx, float* partial, int T, int D, int dtype, hipStream_t st) {
+  int rc;
+  if (dtype == CSMOE_BF16) {
+    const int cpl = (D / 8 + 63) / 64;           // <= 8 for D <= 4096
+    rc = cpl <= 2 ? launch_ln_bwd<bf16, 2, true>(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, st)
+       : cpl <= 4 ? launch_ln_bwd<bf16, 4, true>(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, st)
+                  : launch_ln_bwd<bf16, 8, false>(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, st);
+  } else {
+    const int cpl = (D / 4 + 63) / 64;           // <= 16 for D <= 4096
+    rc = cpl <= 4 ? launch_ln_bwd<float, 4, true>(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, st)
+       : cpl <= 8 ? launch_ln_bwd<float, 8, true>(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, st)
+                  : launch_ln_bwd<float, 16, false>(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, st);
+  }
+  if (rc) return rc;
+  CSMOE_CHECK_LAUNCH("layernorm_bwd");
+  return CSMOE_OK;
+}

@@ -39,6 +39,13 @@ int k_combine(const void*, const int32_t*, const int32_t*, const float*, const v
 int k_combine_bwd(const void*, const void*, const int32_t*, const float*, void*, float*, int, int, int, int, hipStream_t);
 int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, void*, int, int, hipStream_t);
 int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
+int k_layernorm_max_d(int dtype);
+bool k_layernorm_can_fuse(int dtype, int D, int E);
+int k_layernorm_fwd(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd, int T,
+                    int D, int dtype, const void* wg, void* logits, int E, hipStream_t st);
+int k_layernorm_bwd_blocks(int T);
+int k_layernorm_bwd(const void* dxn, const void* dxn2, const void* x, const void* gamma, const float* mean, const float* rstd,
+                    const void* add, void* dx, float* partial, int T, int D, int dtype, hipStream_t st);
 int k_softplus_mean_bwd(const void*, const void*, const void*, void*, int, int, int, hipStream_t);
 
 static thread_local char g_err[512] = "";
@@ -165,13 +172,13 @@ int csmoe_dispatch_rows_bwd(const void* dxs, const int32_t* slot_of, int K, cons
   return k_combine(dxs, slot_of, nullptr, nullptr, nullptr, add, dx, T, K, D, dtype, CSMOE_COMBINE_DOT, (hipStream_t)stream);
 }
 
-int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias, void* out, int T,
-                  int K, int D, int dtype, int mode, csmoe_stream_t stream) {
+int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias,
+                  const void* residual, void* out, int T, int K, int D, int dtype, int mode, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && K <= 64 && T >= 0 && D > 0, "combine: bad arguments (K<=64)");
   CSMOE_CHECK_ARG(mode >= 0 && mode <= 2, "combine: bad mode %d", mode);
   CSMOE_CHECK_ARG(T == 0 || (y && slot_of && w && out), "combine: null pointer");
   CSMOE_CHECK_ARG(T == 0 || mode == CSMOE_COMBINE_DOT || idx, "combine: idx required for the sequential rounding rule");
-  return k_combine(y, slot_of, idx, w, obias, nullptr, out, T, K, D, dtype, mode, (hipStream_t)stream);
+  return k_combine(y, slot_of, idx, w, obias, residual, out, T, K, D, dtype, mode, (hipStream_t)stream);
 }
 
 int csmoe_combine_bwd(const void* dout, const void* y, const int32_t* perm, const int32_t* slot_of, const float* w, void* dy,
@@ -284,3 +291,37 @@ int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add,
 }
 
 }  // extern "C"
+
+int csmoe_layernorm_gate(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd,
+                         int T, int D, int dtype, const void* w_gate, void* logits, int E, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype), "layernorm_gate: bad dtype %d", dtype);
+  CSMOE_CHECK_ARG(T >= 0 && D > 0 && D <= k_layernorm_max_d(dtype) && D % (dtype == CSMOE_BF16 ? 8 : 4) == 0,
+                  "layernorm_gate: D=%d unsupported (multiple of %d, at most %d)", D, dtype == CSMOE_BF16 ? 8 : 4,
+                  k_layernorm_max_d(dtype));
+  CSMOE_CHECK_ARG(eps >= 0.f, "layernorm_gate: eps < 0");
+  CSMOE_CHECK_ARG((w_gate == nullptr) == (logits == nullptr) && (w_gate == nullptr || E > 0), "layernorm_gate: w_gate / logits / E");
+  if (T == 0) return CSMOE_OK;
+  CSMOE_CHECK_ARG(x && xn && mean && rstd, "layernorm_gate: null pointer");
+  CSMOE_CHECK_ARG(((((uintptr_t)x | (uintptr_t)xn | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_gate) & 15) == 0),
+                  "layernorm_gate: operands must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (w_gate && k_layernorm_can_fuse(dtype, D, E))
+    return k_layernorm_fwd(x, gamma, beta, eps, xn, mean, rstd, T, D, dtype, w_gate, logits, E, st);
+  int rc = k_layernorm_fwd(x, gamma, beta, eps, xn, mean, rstd, T, D, dtype, nullptr, nullptr, 0, st);
+  if (rc || !w_gate) return rc;
+  return csmoe_gate_logits(xn, w_gate, logits, T, D, E, dtype, stream);
+}
+
+int csmoe_layernorm_bwd_blocks(int T) { return k_layernorm_bwd_blocks(T); }
+
+int csmoe_layernorm_bwd(const void* dxn, const void* dxn2, const void* x, const void* gamma, const float* mean, const float* rstd,
+                        const void* add, void* dx, float* partial, int T, int D, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype), "layernorm_bwd: bad dtype %d", dtype);
+  CSMOE_CHECK_ARG(T >= 0 && D > 0 && D <= k_layernorm_max_d(dtype) && D % (dtype == CSMOE_BF16 ? 8 : 4) == 0,
+                  "layernorm_bwd: D=%d unsupported", D);
+  CSMOE_CHECK_ARG(partial, "layernorm_bwd: null pointer");
+  CSMOE_CHECK_ARG(T == 0 || (dxn && x && mean && rstd && dx), "layernorm_bwd: null pointer");
+  CSMOE_CHECK_ARG(((((uintptr_t)x | (uintptr_t)dxn | (uintptr_t)dxn2 | (uintptr_t)gamma | (uintptr_t)add | (uintptr_t)dx) & 15) == 0),
+                  "layernorm_bwd: operands must be 16-byte aligned");
+  return k_layernorm_bwd(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, dtype, (hipStream_t)stream);
+}

@@ -302,7 +302,6 @@ __global__ void __launch_bounds__(256) dispatch_tokens_kernel(const char* x, con
 // =====================================================================================================================
 // Combine  (moe.py:204 / cvmm.py:481-483) and the dispatch backward gather-sum (cvmm.py:544-545)
 // =====================================================================================================================
-constexpr int MAXK = 64;   // one lane per selected slot
 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t* slot_of, const int32_t* idx, const float* w,

@@ -68,6 +68,48 @@ class GateLogits(torch.autograd.Function):
         return dx, dw
 
 
+class LayerNormGate(torch.autograd.Function):
+    """The read side of the block around the layer: xn = LayerNorm(x), logits = xn @ w_gate^T in one
+    launch, plus x itself handed on as the residual so that ITS gradient comes back here and is added inside the LayerNorm
+    backward kernel instead of by a separate accumulation pass.
+    `layer_norm2` + `self.gate(x)` + `residual + results` of SiglipEncoderMoELayer.forward (siglip_smoe.py:152-155, smoe.py:42)."""
+
+    @staticmethod
+    def forward(ctx, x2, gamma, beta, eps: float, w_gate):
+        x2 = x2.contiguous()
+        wg = w_gate.contiguous()
+        if wg.dtype != x2.dtype:
+            wg = wg.to(x2.dtype)
+        g = None if gamma is None else gamma.to(x2.dtype).contiguous()
+        b = None if beta is None else beta.to(x2.dtype).contiguous()
+        xn, mean, rstd, logits = ops.layernorm_gate(x2, g, b, eps, wg)
+        ctx.save_for_backward(x2, g, mean, rstd, xn, wg)
+        ctx.dtypes = (None if gamma is None else gamma.dtype, None if beta is None else beta.dtype, w_gate.dtype)
+        return xn, logits, x2.view_as(x2)
+
+    @staticmethod
+    def backward(ctx, dxn, dlogits, dres):
+        x2, g, mean, rstd, xn, wg = ctx.saved_tensors
+        gd, bd, wd = ctx.dtypes
+        dxn_gate = dwg = None
+        if dlogits is not None:
+            dlogits = dlogits.contiguous()
+            dxn_gate = ops.dense_gemm(dlogits, wg, L.B_KN)               # [T,E] @ [E,D]
+            if ctx.needs_input_grad[4]:
+                dwg = _chunked_dense_wgrad(dlogits, xn, wd)
+        a, b2 = dxn, dxn_gate
+        if a is None:
+            a, b2 = dxn_gate, None
+        if a is None:                                                      # only the residual carries a gradient
+            return dres, None, None, None, dwg
+        want_affine = (gd is not None and ctx.needs_input_grad[1]) or (bd is not None and ctx.needs_input_grad[2])
+        dx, dgamma, dbeta = ops.layernorm_bwd(a.contiguous(), x2, g, mean, rstd, add=None if dres is None else dres.contiguous(),
+                                              want_affine_grads=want_affine, dxn2=None if b2 is None else b2.contiguous())
+        dg = dgamma.to(gd) if (want_affine and gd is not None) else None
+        db = dbeta.to(bd) if (want_affine and bd is not None) else None
+        return dx, dg, db, None, dwg
+
+
 # ======================================================================================================== router
 class RouterSelect(torch.autograd.Function):
     """softmax / top-k / renormalise in one wave-per-token kernel.  Returns (softmax fp32 [T,E], idx int32 [T,K],
@@ -110,7 +152,7 @@ class ExpertTable:
     param_dtype: torch.dtype = torch.float32   # dtype of the gradients handed back
 
 
-def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias):
+def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residual=None):
     T = x2.shape[0]
     bins = ops.bin_tokens(idx, tab.E)
     xs = ops.dispatch_tokens(x2, bins)
@@ -120,7 +162,7 @@ def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias):
                                   epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True)
     y = ops.grouped_gemm(hact, tab.w2_ptrs, tab.layout, ld2, tab.Dout, bins.offsets, tab.E, bias_ptrs=tab.b2_ptrs,
                          epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
-    out = ops.combine(y, bins, idx, w, combine_mode, T, obias=obias)
+    out = ops.combine(y, bins, idx, w, combine_mode, T, obias=obias, residual=residual)
     return out, (bins, xs, hpre, hact, y)
 
 
@@ -199,6 +241,35 @@ class MoEFFNModules(torch.autograd.Function):
             seq = [gW1] + ([gb1] if gb1 is not None else []) + [gW2] + ([gb2] if gb2 is not None else [])
             pg = [g[e] for g in seq for e in range(E)]
         return (dx2, dw, None, None, None, *pg)
+
+
+class MoEFFNModulesResidual(torch.autograd.Function):
+    """MoEFFNModules with the block's residual added in the combine epilogue: out = round(moe_out + residual)
+    (`hidden_states = residual + results`, moe_model/model/multimodal_encoder/siglip_smoe.py:155).  The gradient of the
+    residual input is dout itself."""
+
+    @staticmethod
+    def forward(ctx, x2, residual, w, idx, tab: ExpertTable, combine_mode: int, *params):
+        x2 = x2.contiguous()
+        out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, None, residual=residual.contiguous())
+        ctx.tab, ctx.saved, ctx.w = tab, saved, w
+        ctx.n_params = len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tab = ctx.tab
+        need_params = any(ctx.needs_input_grad[6:])
+        dx2, dw, grads = _ffn_backward(dout, ctx.w, tab, ctx.saved, ctx.needs_input_grad[0], ctx.needs_input_grad[2],
+                                       need_params)
+        ctx.saved = None
+        pg: List[Optional[torch.Tensor]] = [None] * ctx.n_params
+        if grads is not None:
+            gW1, gb1, gW2, gb2 = grads
+            E = tab.E
+            seq = [gW1] + ([gb1] if gb1 is not None else []) + [gW2] + ([gb2] if gb2 is not None else [])
+            pg = [g[e] for g in seq for e in range(E)]
+        return (dx2, dout if ctx.needs_input_grad[1] else None, dw, None, None, None, *pg)
 
 
 class MoEFFNPacked(torch.autograd.Function):

@@ -12,6 +12,8 @@ from .moe import MoeLayer
 
 @register_moe("competesmoe")
 class CompeteSMoE(MoeLayer):
+    _fuses_residual = True        # output = one combine: a block around the layer may add its residual there (moe/block.py)
+
     def __init__(self, in_embed_dim=768, out_embed_dim=768, num_of_experts=4, num_selected=2, expert=None, args=None):
         super().__init__(in_embed_dim, out_embed_dim, num_of_experts, num_selected, expert, args)
         if args is None or not hasattr(args, "rate_flip"):

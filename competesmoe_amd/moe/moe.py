@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
-from ..functional import ExpertTable, GateLogits, MoEFFNModules, RouterSelect, DenseFFN
+from ..functional import ExpertTable, GateLogits, MoEFFNModules, MoEFFNModulesResidual, RouterSelect, DenseFFN
 from .. import ops
 
 
@@ -136,6 +136,10 @@ class MoeLayer(nn.Module):
     # ------------------------------------------------------------------ router (moe.py:113-132; smoe.py:42-44)
     def gate_logits(self, x):
         B, N, D = x.shape
+        pre = getattr(self, "_pre_logits", None)
+        if pre is not None:                       # computed with the LayerNorm by the block around the layer (moe/block.py)
+            self._pre_logits = None
+            return pre.view(B, N, self.gate.weight.shape[0])
         return GateLogits.apply(x.reshape(B * N, D), self.gate.weight).view(B, N, self.gate.weight.shape[0])
 
     def topk_expert(self, gate_logits, num_selected=None):
@@ -194,7 +198,13 @@ class MoeLayer(nn.Module):
         w2 = weights.reshape(B * N, weights.shape[-1])
         if w2.dtype != torch.float32:
             w2 = w2.float()
-        out = MoEFFNModules.apply(x.reshape(B * N, D), w2.contiguous(), idx2.contiguous(), tab, mode, *params)
+        res = getattr(self, "_residual", None)
+        if res is not None and res.shape[0] == B * N and res.shape[1] == tab.Dout:
+            # the block's residual, added in the combine epilogue (moe/block.py); consumed once
+            self._residual = None
+            out = MoEFFNModulesResidual.apply(x.reshape(B * N, D), res, w2.contiguous(), idx2.contiguous(), tab, mode, *params)
+        else:
+            out = MoEFFNModules.apply(x.reshape(B * N, D), w2.contiguous(), idx2.contiguous(), tab, mode, *params)
         return out.view(B, N, out.shape[-1])
 
     def dense_expert(self, i: int, x):

@@ -167,13 +167,52 @@ def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch
 
 
 def combine(y: torch.Tensor, bins: Bins, idx: torch.Tensor, w: torch.Tensor, mode: int, T: int,
-            obias: Optional[torch.Tensor] = None) -> torch.Tensor:
+            obias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     D = y.shape[1]
     out = torch.empty(T, D, dtype=y.dtype, device=y.device)
-    with _timed("combine", (T + bins.n) * D * y.element_size() + bins.n * 4):
-        L.check(lib.csmoe_combine(y.data_ptr(), bins.slot_of.data_ptr(), _ptr(idx), w.data_ptr(), _ptr(obias), out.data_ptr(),
-                                  T, bins.K, D, _dt(y), mode, _stream()), "combine")
+    if residual is not None:
+        assert residual.shape == (T, D) and residual.dtype == y.dtype and residual.is_contiguous()
+    nbytes = (T + bins.n + (T if residual is not None else 0)) * D * y.element_size() + bins.n * 4
+    with _timed("combine", nbytes):
+        L.check(lib.csmoe_combine(y.data_ptr(), bins.slot_of.data_ptr(), _ptr(idx), w.data_ptr(), _ptr(obias), _ptr(residual),
+                                  out.data_ptr(), T, bins.K, D, _dt(y), mode, _stream()), "combine")
     return out
+
+
+def layernorm_gate(x2: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,
+                   w_gate: Optional[torch.Tensor] = None):
+    """xn, mean, rstd[, logits] = LayerNorm(x2) [and xn @ w_gate^T] -- csmoe_layernorm_gate."""
+    T, D = x2.shape
+    xn = torch.empty_like(x2)
+    mean = torch.empty(T, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(T, dtype=torch.float32, device=x2.device)
+    logits, E = None, 0
+    if w_gate is not None:
+        E = w_gate.shape[0]
+        assert w_gate.dtype == x2.dtype and w_gate.is_contiguous() and w_gate.shape[1] == D
+        logits = torch.empty(T, E, dtype=x2.dtype, device=x2.device)
+    with _timed("layernorm_gate", 2 * T * D * x2.element_size()):
+        L.check(lib.csmoe_layernorm_gate(x2.data_ptr(), _ptr(gamma), _ptr(beta), float(eps), xn.data_ptr(), mean.data_ptr(),
+                                         rstd.data_ptr(), T, D, _dt(x2), _ptr(w_gate), _ptr(logits), E, _stream()),
+                "layernorm_gate")
+    return xn, mean, rstd, logits
+
+
+def layernorm_bwd(dxn: torch.Tensor, x2: torch.Tensor, gamma: Optional[torch.Tensor], mean: torch.Tensor, rstd: torch.Tensor,
+                  add: Optional[torch.Tensor] = None, want_affine_grads: bool = True, dxn2: Optional[torch.Tensor] = None):
+    """dx [T,D] (+ add), dgamma [D] fp32, dbeta [D] fp32 -- csmoe_layernorm_bwd + the column sums of its partial rows."""
+    T, D = x2.shape
+    dx = torch.empty_like(x2)
+    nb = int(lib.csmoe_layernorm_bwd_blocks(T))
+    partial = torch.empty(nb, 2 * D, dtype=torch.float32, device=x2.device)
+    with _timed("layernorm_bwd", (3 + (add is not None) + (dxn2 is not None)) * T * D * x2.element_size()):
+        L.check(lib.csmoe_layernorm_bwd(dxn.data_ptr(), _ptr(dxn2), x2.data_ptr(), _ptr(gamma), mean.data_ptr(), rstd.data_ptr(), _ptr(add),
+                                        dx.data_ptr(), partial.data_ptr(), T, D, _dt(x2), _stream()), "layernorm_bwd")
+    if not want_affine_grads:
+        return dx, None, None
+    sums = torch.empty(2 * D, dtype=torch.float32, device=x2.device)
+    L.check(lib.csmoe_dense_colsum(partial.data_ptr(), 2 * D, nb, 2 * D, sums.data_ptr(), L.F32, L.F32, _stream()), "layernorm_bwd sums")
+    return dx, sums[:D], sums[D:]
 
 
 def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: torch.Tensor, want_dw: bool = True):

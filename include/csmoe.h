@@ -111,9 +111,10 @@ int csmoe_dispatch_rows_bwd(const void* dxs, const int32_t* slot_of, int K, cons
                             int dtype, csmoe_stream_t stream);
 /* combine: out[t,:] = sum_k w[t,k] * y[slot_of[t*K+k], :]  (+ obias[:] if non-null) with the rounding rule `mode`
  * (moe.py:204; cvmm.py:481-483).  idx gives the expert of each slot (visit order for COMBINE_SEQ).
- * `scale` multiplies the result (1.0 normally; 0.5 for smoe_share, shard_smoe.py:55 is applied by the caller). */
+ * `residual` [T,D] (may be null) is added last, as one more x.dtype addition: out = round(out + residual) -- the
+ * `hidden_states = residual + results` of the block around the layer (siglip_smoe.py:155; relative_moe_transformer.py:161). */
 int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias,
-                  void* out, int T, int K, int D, int dtype, int mode, csmoe_stream_t stream);
+                  const void* residual, void* out, int T, int K, int D, int dtype, int mode, csmoe_stream_t stream);
 /* combine backward: dy[m,:] = round(w * dout[t,:]) in the binned row space; dw[t,k] = <dout[t,:], y[slot,:]>
  * (y may be null -> dw not written).  (autograd of moe.py:204; cvmm.py:497-499,543) */
 int csmoe_combine_bwd(const void* dout, const void* y, const int32_t* perm, const int32_t* slot_of, const float* w,
@@ -154,6 +155,24 @@ int csmoe_grouped_colsum(const void* G, int64_t ldg, const int32_t* offsets, int
                          int dtype, int out_dtype, csmoe_stream_t stream);
 
 int csmoe_dense_colsum(const void* G, int64_t ldg, int M, int N, void* out, int dtype, int out_dtype, csmoe_stream_t stream);
+
+/* ---- the MoE half of a pre-LN block around the layer: out = x + MoE(LayerNorm(x))  (SURVEY.md section 8 f1;
+ *      siglip_smoe.py:141-157 SiglipEncoderMoELayer.forward; relative_moe_transformer.py:153-161, preln) ----
+ * LayerNorm over the last dimension with fp32 statistics (torch.nn.LayerNorm semantics): xn = (x - mean) * rstd * gamma + beta,
+ * mean/rstd [T] fp32 are kept for the backward.  gamma / beta may be null.  With w_gate != null the router's gate projection is
+ * computed from the rounded xn in the same call: logits[T,E] = xn @ w_gate^T (gate of moe.py:46 / F.linear(x, w_gate) moe.py:121);
+ * for bf16, E <= 64 and D % 64 == 0 this is ONE kernel (the normalised rows never leave LDS between the two steps), otherwise
+ * the gate GEMM of csmoe_gate_logits follows on the same stream.  D <= 4096, D % 8 == 0 (bf16) / D % 4 == 0 (fp32). */
+int csmoe_layernorm_gate(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd,
+                         int T, int D, int dtype, const void* w_gate, void* logits, int E, csmoe_stream_t stream);
+/* LayerNorm backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxn * gamma, xhat = (x - mean) * rstd.  With
+ * dxn2 != null the gradient of xn is round(dxn + dxn2) (expert path + gate path, summed as autograd would).  With
+ * add != null the residual-path gradient is added in the same pass: dx = round(dx) + add.  `partial` receives
+ * csmoe_layernorm_bwd_blocks(T) rows of [2][D] fp32 (row sums of dxn * xhat and of dxn): their column sums (csmoe_dense_colsum)
+ * are dgamma and dbeta -- deterministic, no atomics. */
+int csmoe_layernorm_bwd(const void* dxn, const void* dxn2, const void* x, const void* gamma, const float* mean, const float* rstd,
+                        const void* add, void* dx, float* partial, int T, int D, int dtype, csmoe_stream_t stream);
+int csmoe_layernorm_bwd_blocks(int T);
 
 /* ---- competition affinity ----------------------------------------------------------------------------
  * aff[r] = mean_d softplus(y[r, d]) rounded to dtype  (competesmoe.py:242; pretrain competesmoe.py:401) and its

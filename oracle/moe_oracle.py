@@ -254,6 +254,15 @@ def llava_shared_forward(x, w_gate, experts, act, k, args, mode: str, out_dim=No
 # --------------------------------------------------------------------------------------------
 # Competition schedule (competesmoe.py:35-176 / pretrain competesmoe.py:123-273)
 # --------------------------------------------------------------------------------------------
+def llava_block_forward(x, ln_weight, ln_bias, eps, moe_forward):
+    """The MoE half of SiglipEncoderMoELayer.forward (moe_model/model/multimodal_encoder/siglip_smoe.py:152-155):
+    residual + moelayer(layer_norm2(residual)).  `moe_forward(xn)` is one of the llava_*_forward functions above (closure over
+    its weights); returns (hidden, aux, infor, stages, xn)."""
+    xn = F.layer_norm(x, (x.shape[-1],), ln_weight, ln_bias, eps)
+    out, aux, infor, st = moe_forward(xn)
+    return x + out, aux, infor, st, xn
+
+
 def make_prob_flips(flip_steps: int, rate_flip: float, max_compete_in_iter: int,
                     prev: Dict[int, torch.Tensor]) -> torch.Tensor:
     """One `torch.rand(1)` per slot; cap layers competing per step by shifting left then right (:108-130)."""
