@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=2048)
     ap.add_argument("--competition", action="store_true", help="time the CompeteSMoE competition step (every expert dense + sparse recompute) instead of the sparse smoe step")
+    ap.add_argument("--block", action="store_true", help="time the block around the layer, x + MoE(LayerNorm(x)) (SURVEY.md section 8 f1), with the fused LayerNorm+gate / residual-combine kernels")
+    ap.add_argument("--block-unfused", action="store_true", help="same block composed from torch LayerNorm, the plain layer and a torch add (A/B for --block)")
     ap.add_argument("--force-ep", action="store_true", help="use the expert-parallel layer even with one rank (smoke-tests the N>1 code path)")
     return ap.parse_args()
 
@@ -146,6 +148,12 @@ def main():
         layer = make_layer(a, dev, dt, E_local=a.experts // world, seed=1 + rank)
     else:
         layer = make_layer(a, dev, dt)
+    blk = ln = None
+    if a.block or a.block_unfused:
+        ln = nn.LayerNorm(D, eps=1e-6).to(dev).to(dt)
+        if a.block:
+            from competesmoe_amd.moe import MoEBlock
+            blk = MoEBlock(ln, layer)
     x = torch.randn(Bsz, Nseq, D, device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(rank)).to(dt)
     dy = torch.randn(Bsz, Nseq, D, device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(2 + rank)).to(dt)
     x.requires_grad_(True)
@@ -155,7 +163,14 @@ def main():
         for p in layer.parameters():
             p.grad = None
         x.grad = None
-        out, aux, _, _ = layer(x)
+        if blk is not None:
+            out, aux, _, _ = blk(x)
+        elif ln is not None:
+            ln.weight.grad = ln.bias.grad = None
+            out, aux, _, _ = layer(ln(x))
+            out = x + out
+        else:
+            out, aux, _, _ = layer(x)
         torch.autograd.backward([out, aux.float()], [dy, one])
 
     def fence():
@@ -209,7 +224,7 @@ def main():
             "metric": "MoE-layer fwd+bwd tokens/sec at d_model=4096, 64 experts top-2", "value": round(total_tokens * a.steps / el, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
+            "config": {"workload": ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
                                    f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, Linear+bias/GELU experts, "
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
                        "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,

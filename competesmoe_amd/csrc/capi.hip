@@ -40,9 +40,8 @@ int k_combine_bwd(const void*, const void*, const int32_t*, const float*, void*,
 int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, void*, int, int, hipStream_t);
 int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
 int k_layernorm_max_d(int dtype);
-bool k_layernorm_can_fuse(int dtype, int D, int E);
 int k_layernorm_fwd(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd, int T,
-                    int D, int dtype, const void* wg, void* logits, int E, hipStream_t st);
+                    int D, int dtype, hipStream_t st);
 int k_layernorm_bwd_blocks(int T);
 int k_layernorm_bwd(const void* dxn, const void* dxn2, const void* x, const void* gamma, const float* mean, const float* rstd,
                     const void* add, void* dx, float* partial, int T, int D, int dtype, hipStream_t st);
@@ -305,9 +304,7 @@ int csmoe_layernorm_gate(const void* x, const void* gamma, const void* beta, flo
   CSMOE_CHECK_ARG(((((uintptr_t)x | (uintptr_t)xn | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_gate) & 15) == 0),
                   "layernorm_gate: operands must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (w_gate && k_layernorm_can_fuse(dtype, D, E))
-    return k_layernorm_fwd(x, gamma, beta, eps, xn, mean, rstd, T, D, dtype, w_gate, logits, E, st);
-  int rc = k_layernorm_fwd(x, gamma, beta, eps, xn, mean, rstd, T, D, dtype, nullptr, nullptr, 0, st);
+  int rc = k_layernorm_fwd(x, gamma, beta, eps, xn, mean, rstd, T, D, dtype, st);
   if (rc || !w_gate) return rc;
   return csmoe_gate_logits(xn, w_gate, logits, T, D, E, dtype, stream);
 }

@@ -335,6 +335,24 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
       float acc[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+      // the residual / extra addend of this chunk: one vector load issued ahead of the K gathers
+      float addv[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) addv[v] = 0.f;
+      if (add && live) {
+        const T* arow = add + (int64_t)t * D + d0;
+        if constexpr (VEC == 8) {
+          bf16x8 r8 = *(const bf16x8*)arow;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) addv[v] = (float)r8[v];
+        } else if constexpr (VEC == 4) {
+          f32x4 r4 = *(const f32x4*)arow;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) addv[v] = r4[v];
+        } else {
+          addv[0] = DT<T>::ld(arow);
+        }
+      }
       for (int kk = 0; kk < K; ++kk) {
         const int src = __ffsll((unsigned long long)__ballot(lane < K && rank == kk)) - 1;
         const int sl = __shfl(myslot, src, 64);
@@ -375,7 +393,7 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
         float r = acc[v];
         if (mode == CSMOE_COMBINE_DOT) r = DT<T>::rnd(r);
         if (obias) r = DT<T>::rnd(r + DT<T>::ld(obias + d0 + v));
-        if (add) r = DT<T>::rnd(r + DT<T>::ld(add + (int64_t)t * D + d0 + v));
+        if (add) r = DT<T>::rnd(r + addv[v]);
         acc[v] = r;
       }
       T* o = out + (int64_t)t * D + d0;

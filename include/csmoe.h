@@ -160,9 +160,9 @@ int csmoe_dense_colsum(const void* G, int64_t ldg, int M, int N, void* out, int 
  *      siglip_smoe.py:141-157 SiglipEncoderMoELayer.forward; relative_moe_transformer.py:153-161, preln) ----
  * LayerNorm over the last dimension with fp32 statistics (torch.nn.LayerNorm semantics): xn = (x - mean) * rstd * gamma + beta,
  * mean/rstd [T] fp32 are kept for the backward.  gamma / beta may be null.  With w_gate != null the router's gate projection is
- * computed from the rounded xn in the same call: logits[T,E] = xn @ w_gate^T (gate of moe.py:46 / F.linear(x, w_gate) moe.py:121);
- * for bf16, E <= 64 and D % 64 == 0 this is ONE kernel (the normalised rows never leave LDS between the two steps), otherwise
- * the gate GEMM of csmoe_gate_logits follows on the same stream.  D <= 4096, D % 8 == 0 (bf16) / D % 4 == 0 (fp32). */
+ * computed from the rounded xn by the same call (second launch on the stream: the gate GEMM of csmoe_gate_logits reads the rows
+ * the LayerNorm just wrote): logits[T,E] = xn @ w_gate^T (gate of moe.py:46 / F.linear(x, w_gate) moe.py:121).
+ * D <= 4096, D % 8 == 0 (bf16) / D % 4 == 0 (fp32), 16-byte aligned operands. */
 int csmoe_layernorm_gate(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd,
                          int T, int D, int dtype, const void* w_gate, void* logits, int E, csmoe_stream_t stream);
 /* LayerNorm backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxn * gamma, xhat = (x - mean) * rstd.  With
