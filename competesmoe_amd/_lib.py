@@ -45,6 +45,8 @@ SIGNATURES = {
     "csmoe_dense_colsum": (_i, [_p, _l, _i, _i, _p, _i, _i, _p]),
     "csmoe_softplus_mean": (_i, [_p, _p, _i, _i, _i, _p]),
     "csmoe_softplus_mean_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "csmoe_pair_cosine": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "csmoe_pair_cosine_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "csmoe_layernorm_gate": (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
     "csmoe_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "csmoe_layernorm_bwd_blocks": (_i, [_i]),

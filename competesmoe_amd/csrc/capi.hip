@@ -39,6 +39,8 @@ int k_combine(const void*, const int32_t*, const int32_t*, const float*, const v
 int k_combine_bwd(const void*, const void*, const int32_t*, const float*, void*, float*, int, int, int, int, hipStream_t);
 int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, void*, int, int, hipStream_t);
 int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
+int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st);
+int k_pair_cosine_bwd(const void* y, const float* gscale, void* dy, int T, int K, int D, int dtype, hipStream_t st);
 int k_layernorm_max_d(int dtype);
 int k_layernorm_fwd(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd, int T,
                     int D, int dtype, hipStream_t st);
@@ -290,6 +292,18 @@ int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add,
 }
 
 }  // extern "C"
+
+int csmoe_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && T >= 0 && K > 0 && K <= 8 && D > 0, "pair_cosine: bad arguments (K <= 8)");
+  CSMOE_CHECK_ARG(T == 0 || (y && tok_loss), "pair_cosine: null pointer");
+  return k_pair_cosine(y, tok_loss, T, K, D, dtype, (hipStream_t)stream);
+}
+
+int csmoe_pair_cosine_bwd(const void* y, const float* gscale, void* dy, int T, int K, int D, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && T >= 0 && K > 0 && K <= 8 && D > 0, "pair_cosine_bwd: bad arguments (K <= 8)");
+  CSMOE_CHECK_ARG(T == 0 || (y && gscale && dy), "pair_cosine_bwd: null pointer");
+  return k_pair_cosine_bwd(y, gscale, dy, T, K, D, dtype, (hipStream_t)stream);
+}
 
 int csmoe_layernorm_gate(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd,
                          int T, int D, int dtype, const void* w_gate, void* logits, int E, csmoe_stream_t stream) {

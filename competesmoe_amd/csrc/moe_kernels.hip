@@ -539,35 +539,141 @@ __global__ void __launch_bounds__(256) colsum_bf16x8_kernel(const bf16* G, int64
 // =====================================================================================================================
 // Competition affinity: aff[r] = mean_d softplus(y[r,d])  (competesmoe.py:242) and its backward
 // =====================================================================================================================
-__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+// softplus with torch's threshold (x > 20 -> x); fast exp / log: the value is rounded to x.dtype and averaged over D right after
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : __logf(1.f + __expf(x)); }
+__device__ __forceinline__ float sp_sigmoidf_(float x) { return x > 20.f ? 1.f : __frcp_rn(1.f + __expf(-x)); }
 
-template <typename T>
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16> { static constexpr int N = 8; typedef bf16x8 V; };
+template <> struct Vec16<float> { static constexpr int N = 4; typedef f32x4 V; };
+
+// wave per row, 16-byte accesses when VEC (D % N == 0, 16-byte aligned rows)
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) softplus_mean_kernel(const T* y, T* aff, int R, int D) {
+  typedef typename Vec16<T>::V V;
+  constexpr int N = Vec16<T>::N;
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
   for (int r = wave_g; r < R; r += nw) {
     float s = 0.f;
-    for (int d = lane; d < D; d += 64) s += DT<T>::rnd(softplusf_(DT<T>::ld(y + (int64_t)r * D + d)));
+    if constexpr (VEC) {
+      for (int d = lane * N; d < D; d += 64 * N) {
+        const V v = *(const V*)(y + (int64_t)r * D + d);
+#pragma unroll
+        for (int j = 0; j < N; ++j) s += DT<T>::rnd(softplusf_((float)v[j]));
+      }
+    } else {
+      for (int d = lane; d < D; d += 64) s += DT<T>::rnd(softplusf_(DT<T>::ld(y + (int64_t)r * D + d)));
+    }
     s = wave_sum(s);
     if (lane == 0) DT<T>::st(aff + r, s / (float)D);
   }
 }
 
-template <typename T>
+// dy[r,d] = round(round(daff[r] / D) * sigmoid(y[r,d])) (+ dy_add[r,d])
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) softplus_mean_bwd_kernel(const T* y, const T* daff, const T* dy_add, T* dy, int R, int D) {
+  typedef typename Vec16<T>::V V;
+  constexpr int N = Vec16<T>::N;
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
   for (int r = wave_g; r < R; r += nw) {
     const float g = DT<T>::rnd(DT<T>::ld(daff + r) / (float)D);
+    if constexpr (VEC) {
+      for (int d = lane * N; d < D; d += 64 * N) {
+        const int64_t o = (int64_t)r * D + d;
+        const V v = *(const V*)(y + o);
+        V a;
+        if (dy_add) a = *(const V*)(dy_add + o);
+        V out;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          float t = DT<T>::rnd(g * sp_sigmoidf_((float)v[j]));
+          if (dy_add) t = DT<T>::rnd(t + (float)a[j]);
+          out[j] = (T)t;
+        }
+        *(V*)(dy + o) = out;
+      }
+    } else {
+      for (int d = lane; d < D; d += 64) {
+        const int64_t o = (int64_t)r * D + d;
+        float v = DT<T>::rnd(g * sp_sigmoidf_(DT<T>::ld(y + o)));
+        if (dy_add) v = DT<T>::rnd(v + DT<T>::ld(dy_add + o));
+        DT<T>::st(dy + o, v);
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// Diversity loss of the competition step (moe.py:133-171, competesmoe.py:180-218): per token the sum over ordered pairs i != j
+// of the cosine similarity of the K selected experts' outputs, <y_i / max(|y_i|, 1e-12), y_j / max(|y_j|, 1e-12)> in fp32
+// (F.normalize + bmm + zeroed diagonal upstream: 32768 batched 2x4096x2 matmuls, 15 ms through rocBLAS at the headline).
+// One wave per token, K <= 8; forward writes the per-token sum (the caller sums T values and divides by T*K*K), backward
+// recomputes norms and dots and writes dy = g * 2/|y_k| * (s_k - <n_k, s_k> n_k), s_k = sum_{j != k} n_j, in x.dtype.
+// =====================================================================================================================
+constexpr int PC_MAXK = 8;
+
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) pair_cosine_kernel(const T* y, float* tok_loss, const float* gscale, T* dy, int Tn, int K, int D) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int t = wave_g; t < Tn; t += nw) {
+    const T* base = y + (int64_t)t * K * D;
+    float dot[PC_MAXK][PC_MAXK];                 // upper triangle incl. diagonal (norms)
+#pragma unroll
+    for (int i = 0; i < PC_MAXK; ++i)
+#pragma unroll
+      for (int j = 0; j < PC_MAXK; ++j) dot[i][j] = 0.f;
     for (int d = lane; d < D; d += 64) {
-      const int64_t o = (int64_t)r * D + d;
-      float x = DT<T>::ld(y + o);
-      float sg = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
-      float v = DT<T>::rnd(g * sg);
-      if (dy_add) v = DT<T>::rnd(v + DT<T>::ld(dy_add + o));
-      DT<T>::st(dy + o, v);
+      float v[PC_MAXK];
+#pragma unroll
+      for (int i = 0; i < PC_MAXK; ++i) v[i] = i < K ? DT<T>::ld(base + (int64_t)i * D + d) : 0.f;
+#pragma unroll
+      for (int i = 0; i < PC_MAXK; ++i)
+#pragma unroll
+        for (int j = i; j < PC_MAXK; ++j)
+          if (j < K) dot[i][j] += v[i] * v[j];
+    }
+    float inv[PC_MAXK];
+#pragma unroll
+    for (int i = 0; i < PC_MAXK; ++i)
+#pragma unroll
+      for (int j = i; j < PC_MAXK; ++j)
+        if (j < K) dot[i][j] = wave_sum(dot[i][j]);
+#pragma unroll
+    for (int i = 0; i < PC_MAXK; ++i) inv[i] = i < K ? 1.f / fmaxf(sqrtf(dot[i][i]), 1e-12f) : 0.f;
+    if constexpr (!BWD) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < PC_MAXK; ++i)
+#pragma unroll
+        for (int j = i + 1; j < PC_MAXK; ++j)
+          if (j < K) s += 2.f * dot[i][j] * inv[i] * inv[j];
+      if (lane == 0) tok_loss[t] = s;
+    } else {
+      const float g2 = 2.f * gscale[0];
+      // <n_k, s_k> = sum_{j != k} cos(k, j)
+      float ns[PC_MAXK];
+#pragma unroll
+      for (int k = 0; k < PC_MAXK; ++k) {
+        ns[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < PC_MAXK; ++j)
+          if (j < K && j != k) ns[k] += (j > k ? dot[k][j] : dot[j][k]) * inv[k] * inv[j];
+      }
+      T* dbase = dy + (int64_t)t * K * D;
+      for (int d = lane; d < D; d += 64) {
+        float n[PC_MAXK], tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < PC_MAXK; ++i) { n[i] = i < K ? DT<T>::ld(base + (int64_t)i * D + d) * inv[i] : 0.f; tot += n[i]; }
+#pragma unroll
+        for (int k = 0; k < PC_MAXK; ++k)
+          if (k < K) DT<T>::st(dbase + (int64_t)k * D + d, g2 * inv[k] * ((tot - n[k]) - ns[k] * n[k]));
+      }
     }
   }
 }
@@ -718,22 +824,52 @@ int k_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int sing
 
 int k_softplus_mean(const void* y, void* aff, int R, int D, int dtype, hipStream_t st) {
   if (R == 0) return CSMOE_OK;
-  if (dtype == CSMOE_BF16)
-    hipLaunchKernelGGL((softplus_mean_kernel<bf16>), dim3(stride_grid(R)), dim3(256), 0, st, (const bf16*)y, (bf16*)aff, R, D);
-  else
-    hipLaunchKernelGGL((softplus_mean_kernel<float>), dim3(stride_grid(R)), dim3(256), 0, st, (const float*)y, (float*)aff, R, D);
+  dim3 grid(stride_grid(R)), block(256);
+  const bool al = ((uintptr_t)y & 15) == 0;
+  if (dtype == CSMOE_BF16) {
+    if (D % 8 == 0 && al) hipLaunchKernelGGL((softplus_mean_kernel<bf16, true>), grid, block, 0, st, (const bf16*)y, (bf16*)aff, R, D);
+    else                  hipLaunchKernelGGL((softplus_mean_kernel<bf16, false>), grid, block, 0, st, (const bf16*)y, (bf16*)aff, R, D);
+  } else {
+    if (D % 4 == 0 && al) hipLaunchKernelGGL((softplus_mean_kernel<float, true>), grid, block, 0, st, (const float*)y, (float*)aff, R, D);
+    else                  hipLaunchKernelGGL((softplus_mean_kernel<float, false>), grid, block, 0, st, (const float*)y, (float*)aff, R, D);
+  }
   CSMOE_CHECK_LAUNCH("softplus_mean");
   return CSMOE_OK;
 }
 
 int k_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype, hipStream_t st) {
   if (R == 0) return CSMOE_OK;
-  if (dtype == CSMOE_BF16)
-    hipLaunchKernelGGL((softplus_mean_bwd_kernel<bf16>), dim3(stride_grid(R)), dim3(256), 0, st, (const bf16*)y, (const bf16*)daff,
-                       (const bf16*)dy_add, (bf16*)dy, R, D);
-  else
-    hipLaunchKernelGGL((softplus_mean_bwd_kernel<float>), dim3(stride_grid(R)), dim3(256), 0, st, (const float*)y,
-                       (const float*)daff, (const float*)dy_add, (float*)dy, R, D);
+  dim3 grid(stride_grid(R)), block(256);
+  const bool al = (((uintptr_t)y | (uintptr_t)dy_add | (uintptr_t)dy) & 15) == 0;
+  if (dtype == CSMOE_BF16) {
+    if (D % 8 == 0 && al)
+      hipLaunchKernelGGL((softplus_mean_bwd_kernel<bf16, true>), grid, block, 0, st, (const bf16*)y, (const bf16*)daff, (const bf16*)dy_add, (bf16*)dy, R, D);
+    else
+      hipLaunchKernelGGL((softplus_mean_bwd_kernel<bf16, false>), grid, block, 0, st, (const bf16*)y, (const bf16*)daff, (const bf16*)dy_add, (bf16*)dy, R, D);
+  } else {
+    if (D % 4 == 0 && al)
+      hipLaunchKernelGGL((softplus_mean_bwd_kernel<float, true>), grid, block, 0, st, (const float*)y, (const float*)daff, (const float*)dy_add, (float*)dy, R, D);
+    else
+      hipLaunchKernelGGL((softplus_mean_bwd_kernel<float, false>), grid, block, 0, st, (const float*)y, (const float*)daff, (const float*)dy_add, (float*)dy, R, D);
+  }
   CSMOE_CHECK_LAUNCH("softplus_mean_bwd");
+  return CSMOE_OK;
+}
+
+int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  dim3 grid(stride_grid(T)), block(256);
+  if (dtype == CSMOE_BF16) hipLaunchKernelGGL((pair_cosine_kernel<bf16, false>), grid, block, 0, st, (const bf16*)y, tok_loss, (const float*)nullptr, (bf16*)nullptr, T, K, D);
+  else                     hipLaunchKernelGGL((pair_cosine_kernel<float, false>), grid, block, 0, st, (const float*)y, tok_loss, (const float*)nullptr, (float*)nullptr, T, K, D);
+  CSMOE_CHECK_LAUNCH("pair_cosine");
+  return CSMOE_OK;
+}
+
+int k_pair_cosine_bwd(const void* y, const float* gscale, void* dy, int T, int K, int D, int dtype, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  dim3 grid(stride_grid(T)), block(256);
+  if (dtype == CSMOE_BF16) hipLaunchKernelGGL((pair_cosine_kernel<bf16, true>), grid, block, 0, st, (const bf16*)y, (float*)nullptr, gscale, (bf16*)dy, T, K, D);
+  else                     hipLaunchKernelGGL((pair_cosine_kernel<float, true>), grid, block, 0, st, (const float*)y, (float*)nullptr, gscale, (float*)dy, T, K, D);
+  CSMOE_CHECK_LAUNCH("pair_cosine_bwd");
   return CSMOE_OK;
 }

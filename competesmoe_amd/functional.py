@@ -42,6 +42,25 @@ def _chunked_dense_wgrad(a: torch.Tensor, b: torch.Tensor, out_dtype) -> torch.T
     return part.sum(0).to(out_dtype)
 
 
+def _chunked_dense_colsum(g: torch.Tensor, out_dtype) -> torch.Tensor:
+    """Column sums of a tall dense [M, N] matrix (bias gradient of an always-on / dense-competition expert).  One launch over all
+    M rows has only ceil(N / 512) workgroups (22 at N = 11008 on a 256-CU chip: 0.4 TB/s); the rows are cut into chunks that the
+    grouped column-sum kernel treats as pseudo-experts (fp32 partials, deterministic), followed by one small sum."""
+    M, N = g.shape
+    P = max(1, min(64, M // 512))
+    if P == 1:
+        return ops.dense_colsum(g, out_dtype=out_dtype)
+    key = (M, P, g.device)
+    off = _CHUNK_OFFSETS.get(key)
+    if off is None:
+        step = (M + P - 1) // P
+        off = _CHUNK_OFFSETS[key] = torch.clamp(torch.arange(P + 1, dtype=torch.int64) * step, max=M).int().to(g.device)
+    part = torch.empty(P, N, dtype=torch.float32, device=g.device)
+    ptrs = part.data_ptr() + torch.arange(P, device=g.device, dtype=torch.int64) * (N * 4)
+    ops.grouped_colsum(g, off, P, part, ptrs)
+    return part.sum(0).to(out_dtype)
+
+
 class GateLogits(torch.autograd.Function):
     """logits = x @ w_gate^T rounded to x.dtype -- `self.gate(x)` (moe_model/model/moe/smoe.py:42) /
     `F.linear(x, self.w_gate)` (moe_pretrain_model/layers/moe/moe.py:121)."""
@@ -321,7 +340,7 @@ class MoEFFNPacked(torch.autograd.Function):
             if ctx.has[0]:
                 gb = gb1 if gb1.dtype == ctx.bias_dtype else gb1.to(ctx.bias_dtype)
         if ctx.has[1] and ctx.needs_input_grad[6]:
-            gob = ops.dense_colsum(dout.contiguous(), out_dtype=ctx.ob_dtype)
+            gob = _chunked_dense_colsum(dout.contiguous(), ctx.ob_dtype)
         return dx2, dw, None, gk, gv, gb, gob, None, None
 
 
@@ -353,11 +372,11 @@ class DenseFFN(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             gw2 = ops.dense_wgrad(dy, hact, out_dtype=dt_w2) if layout == L.B_NK else ops.dense_wgrad(hact, dy, out_dtype=dt_w2)
         if dt_b2 is not None and ctx.needs_input_grad[4]:
-            gb2 = ops.dense_colsum(dy, out_dtype=dt_b2)
+            gb2 = _chunked_dense_colsum(dy, dt_b2)
         if ctx.needs_input_grad[1]:
             gw1 = ops.dense_wgrad(dh, x2, out_dtype=dt_w1) if layout == L.B_NK else ops.dense_wgrad(x2, dh, out_dtype=dt_w1)
         if dt_b1 is not None and ctx.needs_input_grad[2]:
-            gb1 = ops.dense_colsum(dh, out_dtype=dt_b1)
+            gb1 = _chunked_dense_colsum(dh, dt_b1)
         if ctx.needs_input_grad[0]:
             dx = ops.dense_gemm(dh, w1o, _flip(layout))
         return dx, gw1, gb1, gw2, gb2, None, None
@@ -378,3 +397,25 @@ class SoftplusMean(torch.autograd.Function):
     def backward(ctx, daff):
         (y2,) = ctx.saved_tensors
         return ops.softplus_mean_bwd(y2, daff.contiguous().to(y2.dtype))
+
+
+# ======================================================================================================== diversity loss
+class DiversityLoss(torch.autograd.Function):
+    """mean over T*K*K of the off-diagonal cosine similarities of the K selected experts' outputs (diagonal zeroed, counted in
+    the mean) -- `experts_diversity_loss` (moe_model/model/moe/moe.py:133-171, competesmoe.py:180-218; pretrain
+    competesmoe.py).  fp32 math on x.dtype inputs like the reference's `.to(torch.float32)`; K <= 8."""
+
+    @staticmethod
+    def forward(ctx, topk_out):
+        y3 = topk_out.reshape(-1, topk_out.shape[-2], topk_out.shape[-1]).contiguous()
+        T, K, _ = y3.shape
+        ctx.save_for_backward(y3)
+        ctx.shape = topk_out.shape
+        return ops.pair_cosine(y3).sum() / float(T * K * K)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y3,) = ctx.saved_tensors
+        T, K, _ = y3.shape
+        gs = (g.float() / float(T * K * K)).reshape(1).contiguous()
+        return ops.pair_cosine_bwd(y3, gs).view(ctx.shape)

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
-from ..functional import ExpertTable, GateLogits, MoEFFNModules, MoEFFNModulesResidual, RouterSelect, DenseFFN
+from ..functional import ExpertTable, GateLogits, MoEFFNModules, MoEFFNModulesResidual, RouterSelect, DenseFFN, DiversityLoss
 from .. import ops
 
 
@@ -126,6 +126,8 @@ class MoeLayer(nn.Module):
 
     def experts_diversity_loss(self, expert_outputs):
         """moe.py:133-171 / competesmoe.py:180-218."""
+        if expert_outputs.shape[-2] <= 8:          # one kernel instead of normalize + 32k tiny batched matmuls
+            return DiversityLoss.apply(expert_outputs)
         eo = expert_outputs.to(torch.float32)
         B, N, K, D = eo.shape
         nrm = nn.functional.normalize(eo, p=2, dim=-1).view(B * N, K, D)

@@ -302,3 +302,20 @@ def softplus_mean_bwd(y: torch.Tensor, daff: torch.Tensor, dy_add: Optional[torc
     L.check(lib.csmoe_softplus_mean_bwd(y.data_ptr(), daff.data_ptr(), _ptr(dy_add), dy.data_ptr(), R, D, _dt(y), _stream()),
             "softplus_mean_bwd")
     return dy
+
+
+def pair_cosine(y3: torch.Tensor) -> torch.Tensor:
+    """tok_loss[T] (fp32) of csmoe_pair_cosine for y3 [T, K, D]."""
+    T, K, D = y3.shape
+    out = torch.empty(T, dtype=torch.float32, device=y3.device)
+    with _timed("pair_cosine", T * K * D * y3.element_size()):
+        L.check(lib.csmoe_pair_cosine(y3.data_ptr(), out.data_ptr(), T, K, D, _dt(y3), _stream()), "pair_cosine")
+    return out
+
+
+def pair_cosine_bwd(y3: torch.Tensor, gscale: torch.Tensor) -> torch.Tensor:
+    T, K, D = y3.shape
+    dy = torch.empty_like(y3)
+    with _timed("pair_cosine_bwd", 2 * T * K * D * y3.element_size()):
+        L.check(lib.csmoe_pair_cosine_bwd(y3.data_ptr(), gscale.data_ptr(), dy.data_ptr(), T, K, D, _dt(y3), _stream()), "pair_cosine_bwd")
+    return dy

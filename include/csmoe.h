@@ -156,6 +156,12 @@ int csmoe_grouped_colsum(const void* G, int64_t ldg, const int32_t* offsets, int
 
 int csmoe_dense_colsum(const void* G, int64_t ldg, int M, int N, void* out, int dtype, int out_dtype, csmoe_stream_t stream);
 
+/* diversity loss of the competition step (moe.py:133-171, competesmoe.py:180-218): tok_loss[t] = sum over ordered pairs
+ * i != j of <y[t,i,:] / max(|y[t,i,:]|, 1e-12), y[t,j,:] / ...> (fp32), y = [T, K, D] selected expert outputs, K <= 8; the loss
+ * is sum_t tok_loss[t] / (T*K*K).  Backward: dy = gscale[0] * d(sum_t tok_loss)/dy in x.dtype (gscale: device scalar). */
+int csmoe_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, csmoe_stream_t stream);
+int csmoe_pair_cosine_bwd(const void* y, const float* gscale, void* dy, int T, int K, int D, int dtype, csmoe_stream_t stream);
+
 /* ---- the MoE half of a pre-LN block around the layer: out = x + MoE(LayerNorm(x))  (SURVEY.md section 8 f1;
  *      siglip_smoe.py:141-157 SiglipEncoderMoELayer.forward; relative_moe_transformer.py:153-161, preln) ----
  * LayerNorm over the last dimension with fp32 statistics (torch.nn.LayerNorm semantics): xn = (x - mean) * rstd * gamma + beta,

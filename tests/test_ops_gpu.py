@@ -366,3 +366,28 @@ def test_argument_errors_raise():
         ops.router_select(x.half(), 2, 0, False)   # unsupported dtype
     with pytest.raises(ValueError):
         ops.bin_tokens(torch.zeros(4, 2, dtype=torch.int64, device=DEV), 4)
+
+
+# ---------------------------------------------------------------------------------------------------- diversity loss
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,K,D", [(50, 2, 64), (129, 3, 200), (33, 4, 4096), (7, 8, 96), (64, 1, 32)])
+def test_pair_cosine_matches_torch_autograd(dt, T, K, D):
+    """DiversityLoss (csmoe_pair_cosine / _bwd) against the reference formula (normalize -> bmm -> zero diagonal -> mean) and
+    its autograd, both evaluated in fp32 on the same x.dtype inputs.  fp32 1e-5, bf16 gradients 2e-3 (rounded to bf16)."""
+    from competesmoe_amd.functional import DiversityLoss
+    from tests.golden_util import rel_l2
+    g = torch.Generator(device=DEV).manual_seed(T * 13 + K)
+    y = (torch.randn(2, T, K, D, device=DEV, generator=g) * 1.5 + 0.2).to(dt).requires_grad_(True)
+    loss = DiversityLoss.apply(y)
+    (loss * 3.0).backward()
+    yr = y.detach().clone().requires_grad_(True)
+    eo = yr.to(torch.float32)
+    nrm = torch.nn.functional.normalize(eo, p=2, dim=-1).view(-1, K, D)
+    sim = torch.bmm(nrm, nrm.transpose(1, 2)) * (1 - torch.eye(K, device=DEV))
+    ref = sim.mean()
+    (ref * 3.0).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    if K > 1:
+        assert rel_l2(y.grad, yr.grad) <= (1e-5 if dt == torch.float32 else 4e-3)
+    else:
+        assert float(y.grad.abs().max()) == 0.0
