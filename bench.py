@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--competition", action="store_true", help="time the CompeteSMoE competition step (every expert dense + sparse recompute) instead of the sparse smoe step")
     ap.add_argument("--block", action="store_true", help="time the block around the layer, x + MoE(LayerNorm(x)) (SURVEY.md section 8 f1), with the fused LayerNorm+gate / residual-combine kernels")
     ap.add_argument("--block-unfused", action="store_true", help="same block composed from torch LayerNorm, the plain layer and a torch add (A/B for --block)")
+    ap.add_argument("--stack", default="llava", choices=["llava", "pretrain"], help="pretrain: the LM-pretrain stack's `smoe` layer (packed fp32 master weights keys/values, ReLU, no bias, bf16 autocast: the cvmm path) instead of the LLaVA-stack layer")
     ap.add_argument("--force-ep", action="store_true", help="use the expert-parallel layer even with one rank (smoke-tests the N>1 code path)")
     return ap.parse_args()
 
@@ -84,6 +85,22 @@ def make_layer(a, dev, dt, E_local=None, seed=1):
     if a.skew:
         with torch.no_grad():
             layer.gate.weight[:8] += 2.0 / (D ** 0.5)
+    return layer
+
+
+def make_pretrain_layer(a, dev):
+    """pretrain-stack `smoe` (moe_pretrain_model/layers/moe/smoe.py): fp32 master parameters, the step runs under bf16 autocast."""
+    import torch.nn.functional as F
+    from competesmoe_amd.pretrain import get_moe
+    args = types.SimpleNamespace(moe_name="smoe", stop_after=10, warm_up=0.0, rate_flip=1.0, max_compete_in_iter=8,
+                                 balance_loss_coef=0.01, balance_loss_coef_comp=0.02, router_loss_coef=0.03, router_theta=0.5,
+                                 in_topk=False, hybrid=False, tribrid=False, balance_affinity=False, is_cosine=False,
+                                 is_norm_weight=False, norm_sigmoid=False, scale_weight=1.0, test_only=False)
+    with torch.device(dev):
+        layer = get_moe("smoe")(a.d_model, a.experts, a.d_ff, n_heads=a.topk, activation=F.relu, bias=False, log_interval=None,
+                                args=args)
+    layer = layer.to(dev).train()
+    layer.regularization_present = True
     return layer
 
 
@@ -143,7 +160,10 @@ def main():
     T, D = a.tokens, a.d_model
     Bsz = max(1, T // a.seq)
     Nseq = T // Bsz
-    if world > 1 or a.force_ep:
+    if a.stack == "pretrain":
+        assert world == 1 and not (a.force_ep or a.block or a.block_unfused or a.competition), "--stack pretrain: single-GPU smoe step only"
+        layer = make_pretrain_layer(a, dev)
+    elif world > 1 or a.force_ep:
         assert a.experts % world == 0, "experts must divide over ranks"
         layer = make_layer(a, dev, dt, E_local=a.experts // world, seed=1 + rank)
     else:
@@ -158,11 +178,21 @@ def main():
     dy = torch.randn(Bsz, Nseq, D, device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(2 + rank)).to(dt)
     x.requires_grad_(True)
     one = torch.ones((), device=dev)
+    x32 = dy32 = None
+    if a.stack == "pretrain":          # the LM's residual stream is fp32 under autocast
+        x32 = x.detach().float().requires_grad_(True)
+        dy32 = dy.float()
 
     def step():
         for p in layer.parameters():
             p.grad = None
         x.grad = None
+        if a.stack == "pretrain":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = layer(x32, id_layer=0)
+                reg = sum(layer.get_reg_loss().values())
+            torch.autograd.backward([out, reg.float()], [dy32.to(out.dtype), one])
+            return
         if blk is not None:
             out, aux, _, _ = blk(x)
         elif ln is not None:
@@ -224,7 +254,7 @@ def main():
             "metric": "MoE-layer fwd+bwd tokens/sec at d_model=4096, 64 experts top-2", "value": round(total_tokens * a.steps / el, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
+            "config": {"workload": ("pretrain-stack layer (packed fp32 master weights, ReLU, no bias, bf16 autocast; weights cast to bf16 every step): " if a.stack == "pretrain" else "") + ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
                                    f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, Linear+bias/GELU experts, "
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
                        "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
