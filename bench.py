@@ -244,8 +244,17 @@ def main():
             big = {k: v for k, v in gemm.items() if k != "gate_wgrad"}
             tot_ms = sum(v["ms"] * v["calls"] for v in big.values()) / a.steps
             tot_fl = sum(v["work"] * v["calls"] for v in big.values()) / a.steps
+            # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value
+            # comes from the committed rocprofv3 --pmc passes of the same command (profiles/r01/traffic.json), null if absent
+            traffic = None
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "traffic.json")) as fh:
+                    traffic = json.load(fh).get(dom)
+            except (OSError, ValueError):
+                pass
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "traffic_note": "bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01); algorithmic bytes of this launch: 7.75e9" if traffic and dom == "grouped_wgrad_tn" else None,
                     "all_grouped_gemm": {"ms_per_step": round(tot_ms, 3), "TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
                                          "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4)},
                     "hbm_kernels": {k: {"GB/s": d["GB/s"], "frac": round(d["GB/s"] / HBM_PEAK_GBS, 4)}
