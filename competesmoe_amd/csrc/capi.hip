@@ -26,7 +26,7 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
                  const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
                  hipStream_t st);
 int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
-              void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st);
+              void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st, const int32_t* xcd_order = nullptr);
 int k_router_select(const void*, int, int, int, int, int, int, float*, int32_t*, float*, hipStream_t);
 int k_router_select_bwd(const void*, int, int, int, int, int, int, const float*, const int32_t*, const float*, const float*,
                         const float*, void*, hipStream_t);
@@ -40,6 +40,7 @@ int k_combine_bwd(const void*, const void*, const int32_t*, const float*, void*,
 int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, void*, int, int, hipStream_t);
 int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
 int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st);
+int k_expert_order(const int32_t* offsets, int E, int32_t* order, hipStream_t st);
 int k_pair_cosine_bwd(const void* y, const float* gscale, void* dy, int T, int K, int D, int dtype, hipStream_t st);
 int k_layernorm_max_d(int dtype);
 int k_layernorm_fwd(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd, int T,
@@ -235,7 +236,7 @@ int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, in
 
 int csmoe_grouped_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int M, int Na,
                         int Nb, void* const* c_ptrs, int64_t ldc, int dtype, int out_dtype, int accumulate, int force_generic,
-                        csmoe_stream_t stream) {
+                        const int32_t* xcd_order, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && dtype_ok(out_dtype), "grouped_wgrad: bad dtype");
   CSMOE_CHECK_ARG(E > 0 && M >= 0 && Na > 0 && Nb > 0, "grouped_wgrad: bad shape");
   CSMOE_CHECK_ARG(c_ptrs && offsets && (M == 0 || (A && B)), "grouped_wgrad: null pointer");
@@ -244,10 +245,15 @@ int csmoe_grouped_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, 
   hipStream_t st = (hipStream_t)stream;
   if (!force_generic && dtype == CSMOE_BF16 && gg_fast_wgrad_ok(lda, ldb, ldc, M, Na, Nb, A, B)) {
     if (use_v2_wgrad(M, Na, Nb))
-      return gg8_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, out_dtype, accumulate, 0, nullptr, st);
+      return gg8_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, out_dtype, accumulate, 0, nullptr, st, xcd_order);
     return gg_fast_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, out_dtype, accumulate, 0, nullptr, st);
   }
   return gg_generic_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, dtype, out_dtype, accumulate, 0, nullptr, st);
+}
+
+int csmoe_expert_order(const int32_t* offsets, int E, int32_t* order, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(E > 0 && E <= 8192 && offsets && order, "expert_order: bad arguments");
+  return k_expert_order(offsets, E, order, (hipStream_t)stream);
 }
 
 int csmoe_dense_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int Na, int Nb, void* C, int64_t ldc,

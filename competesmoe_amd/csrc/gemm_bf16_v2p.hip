@@ -66,10 +66,16 @@ __device__ __forceinline__ uint64_t sload_b64(const void* ptr) {
   return r;
 }
 
+// v = position in this workgroup's tile list.  Without p.xcd_order: the global tile order (expert-major).  With it: the tiles of
+// the experts dealt to this workgroup's XCD (csmoe_expert_order): entry [x * slots + k] = k-th expert of XCD x, heaviest first
 __device__ __forceinline__ TileW tile_of(const FastArgs& p, int v, int nct, int per_e) {
   TileW t;
   int e = v / per_e;
   int local = v - e * per_e;
+  if (p.xcd_order) {
+    const int slots = (p.E + 7) >> 3;
+    e = (int)(unsigned)sload_b64(p.xcd_order + (blockIdx.x & 7) * slots + e);     // 8-byte scalar load, low word used
+  }
   int row0 = 0, red_len = p.single_M;
   if (p.offsets) {
     const uint64_t oo = sload_b64(p.offsets + e);          // offsets[e], offsets[e + 1]
@@ -109,7 +115,16 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
   const int per_e = nrt * nct;
   const int total = per_e * p.E;
   int v_begin, v_end, v_step;
-  if ((gridDim.x & 7) == 0) {                    // one contiguous chunk of the tile order per XCD (blocks id, id+8 share one)
+  if (p.xcd_order) {
+    // Experts DEALT to the 8 XCDs by row count (a tile's duration is proportional to its expert's rows): every XCD gets whole
+    // experts (their operand panels stay in ITS L2) and about the same number of rows.  With a contiguous expert range per XCD a
+    // skewed router (BASELINE's second regime: 8 hot experts with consecutive indices) put all hot experts on one XCD: 10.6 ms
+    // per launch instead of 6.5.  Only the last slot of an XCD can be empty (E % 8 != 0).
+    const int x = blockIdx.x & 7, slots = (p.E + 7) >> 3;
+    const int last_pos = ((slots - 1) & 1) ? 7 - x : x;
+    const int n_mine = slots - 1 + (8 * (slots - 1) + last_pos < p.E ? 1 : 0);
+    v_begin = blockIdx.x >> 3; v_end = n_mine * per_e; v_step = gridDim.x >> 3;
+  } else if ((gridDim.x & 7) == 0) {             // one contiguous chunk of the tile order per XCD (blocks id, id+8 share one)
     const int x = blockIdx.x & 7, q8 = total >> 3, r8 = total & 7;
     const int cs = (x < r8) ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8;
     v_begin = cs + (blockIdx.x >> 3); v_end = cs + q8 + (x < r8 ? 1 : 0); v_step = gridDim.x >> 3;
@@ -436,12 +451,15 @@ int set_lds2() {
 }  // namespace
 
 int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
-              void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st) {
+              void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st,
+              const int32_t* xcd_order) {
   FastArgs p{};
   p.single_M = single_M; p.single_C = single_C;
   p.R = A; p.ld_r = lda; p.Cflat = B; p.ld_c = ldb; p.offsets = offsets; p.E = E; p.NR = Na; p.NC = Nb;
   p.out_ptrs = c_ptrs; p.ldc = ldc; p.accumulate = accumulate; p.out_f32 = (out_dtype == CSMOE_F32);
   int64_t grid = (int64_t)E * ((Na + BM2 - 1) / BM2) * ((Nb + BN2 - 1) / BN2);
+  // the dealt order needs the persistent grid to be a multiple of 8 (workgroup id % 8 = XCD)
+  p.xcd_order = (offsets && xcd_order && persistent_grid(grid) % 8 == 0 && persistent_grid(grid) < grid) ? xcd_order : nullptr;
   if (grid <= 0) return CSMOE_OK;
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_wgrad: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;

@@ -27,6 +27,7 @@ struct FastArgs {
   void* C; void* C2; const void* aux; int64_t ldc;
   void* const* out_ptrs;                      // wgrad outputs
   int epilogue, act, accumulate, out_f32;
+  const int32_t* xcd_order;                   // persistent wgrad: experts dealt to XCDs (csmoe_expert_order), or null
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {

@@ -678,6 +678,28 @@ __global__ void __launch_bounds__(256) pair_cosine_kernel(const T* y, float* tok
   }
 }
 
+// =====================================================================================================================
+// Experts dealt to the 8 XCDs by row count for the persistent weight-gradient kernel: rank r (0 = most rows, ties by index) goes
+// to XCD (r % 8) in snake order; order[x * slots + k] = the k-th expert of XCD x (slots = ceil(E / 8)), -1 for an empty slot.
+// One workgroup; O(E^2 / 64) per lane.
+// =====================================================================================================================
+__global__ void __launch_bounds__(256) expert_order_kernel(const int32_t* offsets, int E, int32_t* order) {
+  const int slots = (E + 7) >> 3;
+  for (int o = threadIdx.x; o < 8 * slots + 1; o += 256) order[o] = -1;
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const int c = offsets[e + 1] - offsets[e];
+    int r = 0;
+    for (int j = 0; j < E; ++j) {
+      const int cj = offsets[j + 1] - offsets[j];
+      r += (cj > c || (cj == c && j < e)) ? 1 : 0;
+    }
+    const int k = r >> 3, pos = r & 7;
+    const int x = (k & 1) ? 7 - pos : pos;
+    order[x * slots + k] = e;
+  }
+}
+
 inline int stride_grid(int rows) { return std::max(1, std::min((rows + 3) / 4, 4096)); }
 
 }  // namespace
@@ -871,5 +893,11 @@ int k_pair_cosine_bwd(const void* y, const float* gscale, void* dy, int T, int K
   if (dtype == CSMOE_BF16) hipLaunchKernelGGL((pair_cosine_kernel<bf16, true>), grid, block, 0, st, (const bf16*)y, (float*)nullptr, gscale, (bf16*)dy, T, K, D);
   else                     hipLaunchKernelGGL((pair_cosine_kernel<float, true>), grid, block, 0, st, (const float*)y, (float*)nullptr, gscale, (float*)dy, T, K, D);
   CSMOE_CHECK_LAUNCH("pair_cosine_bwd");
+  return CSMOE_OK;
+}
+
+int k_expert_order(const int32_t* offsets, int E, int32_t* order, hipStream_t st) {
+  hipLaunchKernelGGL(expert_order_kernel, dim3(1), dim3(256), 0, st, offsets, E, order);
+  CSMOE_CHECK_LAUNCH("expert_order");
   return CSMOE_OK;
 }

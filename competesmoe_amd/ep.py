@@ -122,9 +122,9 @@ class EPFFN(torch.autograd.Function):
                 return buf.data_ptr() + torch.arange(E, device=dev, dtype=torch.int64) * (buf[0].numel() * es)
 
             gW2 = torch.empty(E, tab.Dout, tab.F, dtype=pd, device=dev)
-            ops.grouped_wgrad(dys, hact, lb.offsets, E, gW2, table(gW2))
+            ops.grouped_wgrad(dys, hact, lb.offsets, E, gW2, table(gW2), xcd_order=lb.xcd_order)
             gW1 = torch.empty(E, tab.F, tab.D, dtype=pd, device=dev)
-            ops.grouped_wgrad(dh, rs, lb.offsets, E, gW1, table(gW1))
+            ops.grouped_wgrad(dh, rs, lb.offsets, E, gW1, table(gW1), xcd_order=lb.xcd_order)
             seq = [gW1]
             if tab.b1_ptrs is not None:
                 gb1 = torch.empty(E, tab.F, dtype=pd, device=dev)

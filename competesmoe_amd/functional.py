@@ -208,14 +208,14 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
 
         if tab.layout == L.B_NK:
             gW2 = torch.empty(E, tab.Dout, tab.F, dtype=pd, device=dev)
-            ops.grouped_wgrad(dy, hact, bins.offsets, E, gW2, table(gW2))
+            ops.grouped_wgrad(dy, hact, bins.offsets, E, gW2, table(gW2), xcd_order=bins.xcd_order)
             gW1 = torch.empty(E, tab.F, tab.D, dtype=pd, device=dev)
-            ops.grouped_wgrad(dh, xs, bins.offsets, E, gW1, table(gW1))
+            ops.grouped_wgrad(dh, xs, bins.offsets, E, gW1, table(gW1), xcd_order=bins.xcd_order)
         else:
             gW2 = torch.empty(E, tab.F, tab.Dout, dtype=pd, device=dev)
-            ops.grouped_wgrad(hact, dy, bins.offsets, E, gW2, table(gW2))
+            ops.grouped_wgrad(hact, dy, bins.offsets, E, gW2, table(gW2), xcd_order=bins.xcd_order)
             gW1 = torch.empty(E, tab.D, tab.F, dtype=pd, device=dev)
-            ops.grouped_wgrad(xs, dh, bins.offsets, E, gW1, table(gW1))
+            ops.grouped_wgrad(xs, dh, bins.offsets, E, gW1, table(gW1), xcd_order=bins.xcd_order)
         gb1 = gb2 = None
         if tab.b2_ptrs is not None:
             gb2 = torch.empty(E, tab.Dout, dtype=pd, device=dev)

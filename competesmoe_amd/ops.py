@@ -112,11 +112,19 @@ def router_select_bwd(scores, K, mode, round_sum_bf16, sm, idx, w, dw, dsm):
 # ------------------------------------------------------------------------------------------------ binning
 class Bins:
     """Binned row space of one routing decision."""
-    __slots__ = ("counts", "offsets", "perm", "slot_of", "n", "E", "K")
+    __slots__ = ("counts", "offsets", "perm", "slot_of", "n", "E", "K", "_xcd_order")
 
     def __init__(self, counts, offsets, perm, slot_of, n, E, K):
         self.counts, self.offsets, self.perm, self.slot_of = counts, offsets, perm, slot_of
         self.n, self.E, self.K = n, E, K
+        self._xcd_order = None
+
+    @property
+    def xcd_order(self) -> torch.Tensor:
+        """Experts dealt to the XCDs by row count (csmoe_expert_order), computed once per routing decision."""
+        if self._xcd_order is None:
+            self._xcd_order = expert_order(self.offsets, self.E)
+        return self._xcd_order
 
 
 def bin_tokens(idx: torch.Tensor, E: int) -> Bins:
@@ -252,14 +260,23 @@ def dense_gemm(A: torch.Tensor, B: torch.Tensor, b_layout: int, bias: Optional[t
     return (Cm, C2) if want_c2 else Cm
 
 
+def expert_order(offsets: torch.Tensor, E: int) -> torch.Tensor:
+    order = torch.empty(8 * ((E + 7) // 8) + 1, dtype=torch.int32, device=offsets.device)
+    L.check(lib.csmoe_expert_order(offsets.data_ptr(), E, order.data_ptr(), _stream()), "expert_order")
+    return order
+
+
 def grouped_wgrad(A: torch.Tensor, B: torch.Tensor, offsets: torch.Tensor, E: int, out: torch.Tensor,
-                  out_ptrs: torch.Tensor, accumulate: bool = False, force_generic: bool = False, tag: str = "grouped_wgrad_tn"):
-    """out[e] = A_e^T @ B_e for every expert; `out` is [E, Na, Nb] (or any buffer the pointers index)."""
+                  out_ptrs: torch.Tensor, accumulate: bool = False, force_generic: bool = False, tag: str = "grouped_wgrad_tn",
+                  xcd_order: Optional[torch.Tensor] = None):
+    """out[e] = A_e^T @ B_e for every expert; `out` is [E, Na, Nb] (or any buffer the pointers index).  `xcd_order`
+    (Bins.xcd_order) balances the persistent kernel under skewed routing."""
     M, Na = A.shape
     Nb = B.shape[1]
     with _timed(tag, 2.0 * M * Na * Nb):
         L.check(lib.csmoe_grouped_wgrad(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), offsets.data_ptr(), E, M, Na, Nb,
-                                        out_ptrs.data_ptr(), Nb, _dt(A), _dt(out), int(accumulate), int(force_generic), _stream()),
+                                        out_ptrs.data_ptr(), Nb, _dt(A), _dt(out), int(accumulate), int(force_generic),
+                                        _ptr(xcd_order), _stream()),
                 "grouped_wgrad")
     return out
 

@@ -144,7 +144,11 @@ int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, in
  * replaces cvmm_backward_kernel3 (cvmm.py:194-345, 421-457) and autograd's per-expert weight grads. */
 int csmoe_grouped_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int M,
                         int Na, int Nb, void* const* c_ptrs, int64_t ldc, int dtype, int out_dtype, int accumulate,
-                        int force_generic, csmoe_stream_t stream);
+                        int force_generic, const int32_t* xcd_order, csmoe_stream_t stream);
+/* Load balance of the persistent weight-gradient kernel under skewed routing: experts dealt to the 8 XCDs by row count (rank r,
+ * most rows first, goes to XCD r % 8 in snake order).  order: 8 * ceil(E / 8) + 1 int32, entry [x * ceil(E/8) + k] = k-th
+ * expert of XCD x or -1.  Computed once per routing decision, passed as `xcd_order` (may be null: contiguous expert ranges). */
+int csmoe_expert_order(const int32_t* offsets, int E, int32_t* order, csmoe_stream_t stream);
 
 /* Dense form: C[Na,Nb] = A[M,Na]^T B[M,Nb]. */
 int csmoe_dense_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int Na, int Nb, void* C, int64_t ldc,

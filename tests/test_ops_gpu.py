@@ -391,3 +391,51 @@ def test_pair_cosine_matches_torch_autograd(dt, T, K, D):
         assert rel_l2(y.grad, yr.grad) <= (1e-5 if dt == torch.float32 else 4e-3)
     else:
         assert float(y.grad.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------- wgrad load balance
+@pytest.mark.parametrize("E", [64, 61, 8, 3, 130])
+def test_expert_order_deals_by_row_count(E):
+    g = torch.Generator().manual_seed(E)
+    counts = torch.randint(0, 500, (E,), generator=g)
+    counts[: min(8, E)] += 3000                       # hot experts with consecutive indices (the skewed regime)
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = counts.cumsum(0)
+    order = ops.expert_order(off.to(DEV), E).cpu()
+    slots = (E + 7) // 8
+    tab = order[: 8 * slots].view(8, slots)
+    seen = sorted(int(v) for v in tab.flatten() if v >= 0)
+    assert seen == list(range(E))                      # every expert exactly once
+    ranks = sorted(range(E), key=lambda e: (-int(counts[e]), e))
+    for r, e in enumerate(ranks):
+        k, pos = r // 8, r % 8
+        x = 7 - pos if k & 1 else pos
+        assert int(tab[x, k]) == e
+    loads = [sum(int(counts[int(e)]) for e in tab[x] if e >= 0) for x in range(8)]
+    if E >= 16:
+        assert max(loads) <= 1.6 * (sum(loads) / 8)    # the hot experts end up on different XCDs
+
+
+def test_wgrad_with_dealt_order_is_bit_identical():
+    E, D, F_ = 16, 512, 768
+    g = torch.Generator(device=DEV).manual_seed(3)
+    counts = torch.tensor([3000, 2500, 40, 0, 700, 1, 256, 257, 900, 33, 512, 64, 2000, 5, 128, 1024])
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = counts.cumsum(0)
+    off = off.to(DEV)
+    M = int(counts.sum())
+    a = torch.randn(M, F_, device=DEV, generator=g).to(torch.bfloat16)
+    b = torch.randn(M, D, device=DEV, generator=g).to(torch.bfloat16)
+    outs = []
+    for order in (None, ops.expert_order(off, E)):
+        out = torch.full((E, F_, D), float("nan"), device=DEV, dtype=torch.bfloat16)
+        ptrs = out.data_ptr() + torch.arange(E, device=DEV, dtype=torch.int64) * (F_ * D * 2)
+        ops.grouped_wgrad(a, b, off, E, out, ptrs, xcd_order=order)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.stack([a[int(off[e]):int(off[e + 1])].float().t() @ b[int(off[e]):int(off[e + 1])].float() for e in range(E)])
+    assert rel_l2_(outs[1].float(), ref) <= 2e-3
+
+
+def rel_l2_(x, y):
+    return float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30))

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--tokens", type=int, default=32768)
     ap.add_argument("--balanced", action="store_true", help="exactly T*K/E rows per expert (no ragged tiles)")
+    ap.add_argument("--deal", action="store_true", help="weight-gradient launches: experts dealt to XCDs by row count (csmoe_expert_order)")
+    ap.add_argument("--skew", type=float, default=0.0, help="add this to the routing scores of experts 0..7 (hot experts)")
     ap.add_argument("--E", type=int, default=64)
     ap.add_argument("--D", type=int, default=4096)
     ap.add_argument("--F", type=int, default=11008)
@@ -28,7 +30,9 @@ def main():
     if a.balanced:
         counts = torch.full((E,), M // E, dtype=torch.int64)
     else:
-        idx = torch.rand(T, E, generator=torch.Generator().manual_seed(0)).topk(K, -1).indices
+        sc = torch.rand(T, E, generator=torch.Generator().manual_seed(0))
+        sc[:, :8] += a.skew
+        idx = sc.topk(K, -1).indices
         counts = torch.bincount(idx.flatten(), minlength=E)
     off = torch.zeros(E + 1, dtype=torch.int32)
     off[1:] = counts.cumsum(0)
@@ -48,13 +52,14 @@ def main():
     gW2 = torch.empty(E, D, F, device=dev, dtype=bf)
     pg1 = gW1.data_ptr() + ar * (F * D * es)
     pg2 = gW2.data_ptr() + ar * (D * F * es)
+    order = ops.expert_order(off, E) if a.deal else None
     runs = {
         "nt1": (lambda: ops.grouped_gemm(xs, p1, L.B_NK, D, F, off, E, bias_ptrs=pb1, epilogue=L.EPI_BIAS_ACT, act=L.ACT_GELU, want_c2=True), 2.0 * M * D * F),
         "nt2": (lambda: ops.grouped_gemm(h, p2, L.B_NK, F, D, off, E), 2.0 * M * D * F),
         "nn1": (lambda: ops.grouped_gemm(xs, p2, L.B_KN, F, F, off, E, epilogue=L.EPI_ACTGRAD, act=L.ACT_GELU, aux=h), 2.0 * M * D * F),
         "nn2": (lambda: ops.grouped_gemm(h, p1, L.B_KN, D, D, off, E), 2.0 * M * D * F),
-        "tn1": (lambda: ops.grouped_wgrad(h, xs, off, E, gW1, pg1), 2.0 * M * D * F),
-        "tn2": (lambda: ops.grouped_wgrad(xs, h, off, E, gW2, pg2), 2.0 * M * D * F),
+        "tn1": (lambda: ops.grouped_wgrad(h, xs, off, E, gW1, pg1, xcd_order=order), 2.0 * M * D * F),
+        "tn2": (lambda: ops.grouped_wgrad(xs, h, off, E, gW2, pg2, xcd_order=order), 2.0 * M * D * F),
     }
     for name in a.which.split(","):
         fn, flops = runs[name]
