@@ -61,6 +61,28 @@ def _chunked_dense_colsum(g: torch.Tensor, out_dtype) -> torch.Tensor:
     return part.sum(0).to(out_dtype)
 
 
+def _grouped_colsum(g: torch.Tensor, offsets: torch.Tensor, E: int, pd) -> torch.Tensor:
+    """Per-expert column sums [E, N] of the binned rows (bias gradients).  One launch has E * ceil(N / 512) workgroups; with few
+    experts (the reference's LLaVA configs use 4) that is a few dozen on a 256-CU chip (0.5 TB/s), so each expert's rows are cut
+    into chunks handled as pseudo-experts (fp32 partials, deterministic) and summed."""
+    N = g.shape[1]
+    dev = g.device
+    wgs = E * ((N + 511) // 512)
+    if wgs >= 256 or g.shape[0] < 4096:
+        out = torch.empty(E, N, dtype=pd, device=dev)
+        es = out.element_size()
+        ops.grouped_colsum(g, offsets, E, out, out.data_ptr() + torch.arange(E, device=dev, dtype=torch.int64) * (N * es))
+        return out
+    P = min(64, max(2, 512 // wgs))
+    cnt = (offsets[1:] - offsets[:-1]).long()
+    j = torch.arange(P, device=dev, dtype=torch.int64)
+    starts = offsets[:-1, None].long() + (cnt[:, None] * j[None, :]) // P             # [E, P]; chunk (e, j) ends where (e, j+1) starts
+    chunk_off = torch.cat([starts.reshape(-1), offsets[-1:].long()]).int()
+    part = torch.empty(E * P, N, dtype=torch.float32, device=dev)
+    ops.grouped_colsum(g, chunk_off, E * P, part, part.data_ptr() + torch.arange(E * P, device=dev, dtype=torch.int64) * (N * 4))
+    return part.view(E, P, N).sum(1).to(pd)
+
+
 class GateLogits(torch.autograd.Function):
     """logits = x @ w_gate^T rounded to x.dtype -- `self.gate(x)` (moe_model/model/moe/smoe.py:42) /
     `F.linear(x, self.w_gate)` (moe_pretrain_model/layers/moe/moe.py:121)."""
@@ -218,11 +240,9 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
             ops.grouped_wgrad(xs, dh, bins.offsets, E, gW1, table(gW1), xcd_order=bins.xcd_order)
         gb1 = gb2 = None
         if tab.b2_ptrs is not None:
-            gb2 = torch.empty(E, tab.Dout, dtype=pd, device=dev)
-            ops.grouped_colsum(dy, bins.offsets, E, gb2, table(gb2))
+            gb2 = _grouped_colsum(dy, bins.offsets, E, pd)
         if tab.b1_ptrs is not None:
-            gb1 = torch.empty(E, tab.F, dtype=pd, device=dev)
-            ops.grouped_colsum(dh, bins.offsets, E, gb1, table(gb1))
+            gb1 = _grouped_colsum(dh, bins.offsets, E, pd)
         grads = (gW1, gb1, gW2, gb2)
     dx2 = None
     if need_dx:
