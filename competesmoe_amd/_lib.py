@@ -46,6 +46,10 @@ SIGNATURES = {
     "csmoe_dense_colsum": (_i, [_p, _l, _i, _i, _p, _i, _i, _p]),
     "csmoe_softplus_mean": (_i, [_p, _p, _i, _i, _i, _p]),
     "csmoe_softplus_mean_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "csmoe_gate_bwd_small_ok": (_i, [_i, _i, _i]),
+    "csmoe_gate_bwd_dx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "csmoe_gate_bwd_dw_ranges": (_i, [_i, _i, _i]),
+    "csmoe_gate_bwd_dw": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "csmoe_pair_cosine": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "csmoe_pair_cosine_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "csmoe_layernorm_gate": (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),

@@ -41,6 +41,11 @@ int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, 
 int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
 int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st);
 int k_expert_order(const int32_t* offsets, int E, int32_t* order, hipStream_t st);
+bool k_gate_small_ok(int D, int E, int dtype, const void* a, const void* b);
+int k_gate_small_fwd(const void* x, const void* wg, void* logits, int T, int D, int E, int dtype, hipStream_t st);
+int k_gate_small_dx(const void* dl, const void* wg, void* dx, int T, int D, int E, int dtype, hipStream_t st);
+int k_gate_small_dw_ranges(int T, int D, int dtype);
+int k_gate_small_dw(const void* dl, const void* x, float* partial, int T, int D, int E, int dtype, int nranges, hipStream_t st);
 int k_pair_cosine_bwd(const void* y, const float* gscale, void* dy, int T, int K, int D, int dtype, hipStream_t st);
 int k_layernorm_max_d(int dtype);
 int k_layernorm_fwd(const void* x, const void* gamma, const void* beta, float eps, void* xn, float* mean, float* rstd, int T,
@@ -109,6 +114,7 @@ int csmoe_gate_logits(const void* x, const void* w_gate, void* logits, int T, in
   CSMOE_CHECK_ARG(w_gate && (T == 0 || (x && logits)), "gate_logits: null pointer");
   if (T == 0) return CSMOE_OK;      // empty batch: zero-row buffers have no address
   hipStream_t st = (hipStream_t)stream;
+  if (k_gate_small_ok(D, E, dtype, x, w_gate)) return k_gate_small_fwd(x, w_gate, logits, T, D, E, dtype, st);
   // one dense "expert" over all T rows: logits = x @ w_gate^T
   if (dtype == CSMOE_BF16 && gg_fast_rowspace_ok(D, D, E, T, E, D, x, logits))
     return gg_fast_rowspace(x, D, nullptr, CSMOE_B_NK, D, nullptr, nullptr, 1, T, E, D, logits, nullptr, nullptr, E,
@@ -249,6 +255,25 @@ int csmoe_grouped_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, 
     return gg_fast_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, out_dtype, accumulate, 0, nullptr, st);
   }
   return gg_generic_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, dtype, out_dtype, accumulate, 0, nullptr, st);
+}
+
+int csmoe_gate_bwd_small_ok(int D, int E, int dtype) { return dtype_ok(dtype) && D > 0 && E > 0 && k_gate_small_ok(D, E, dtype, nullptr, nullptr) ? 1 : 0; }
+
+int csmoe_gate_bwd_dx(const void* dlogits, const void* w_gate, void* dx, int T, int D, int E, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && T >= 0 && D > 0 && E > 0, "gate_bwd_dx: bad arguments");
+  CSMOE_CHECK_ARG(k_gate_small_ok(D, E, dtype, w_gate, dx), "gate_bwd_dx: needs E <= 16, D a multiple of the 16-byte chunk, aligned operands");
+  CSMOE_CHECK_ARG(T == 0 || (dlogits && w_gate && dx), "gate_bwd_dx: null pointer");
+  return k_gate_small_dx(dlogits, w_gate, dx, T, D, E, dtype, (hipStream_t)stream);
+}
+
+int csmoe_gate_bwd_dw_ranges(int T, int D, int dtype) { return dtype_ok(dtype) && T > 0 && D > 0 ? k_gate_small_dw_ranges(T, D, dtype) : 0; }
+
+int csmoe_gate_bwd_dw(const void* dlogits, const void* x, float* partial, int T, int D, int E, int dtype, int nranges,
+                      csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && T >= 0 && D > 0 && E > 0 && nranges > 0, "gate_bwd_dw: bad arguments");
+  CSMOE_CHECK_ARG(k_gate_small_ok(D, E, dtype, x, nullptr), "gate_bwd_dw: needs E <= 16, D a multiple of the 16-byte chunk, aligned operands");
+  CSMOE_CHECK_ARG(T == 0 || (dlogits && x && partial), "gate_bwd_dw: null pointer");
+  return k_gate_small_dw(dlogits, x, partial, T, D, E, dtype, nranges, (hipStream_t)stream);
 }
 
 int csmoe_expert_order(const int32_t* offsets, int E, int32_t* order, csmoe_stream_t stream) {

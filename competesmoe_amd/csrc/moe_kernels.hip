@@ -679,6 +679,108 @@ __global__ void __launch_bounds__(256) pair_cosine_kernel(const T* y, float* tok
 }
 
 // =====================================================================================================================
+// Skinny gate projection for few experts (E <= 16; the reference's LLaVA configs use 4): the 128x128 MFMA tiles of the GEMM path
+// waste >= 7/8 of their columns there (0.09 / 0.17 ms for logits / weight gradient at [12800, 1152] x 4 experts, next to a
+// 3 ms step).  Plain HBM-bound row passes instead: logits = x @ Wg^T, dx = dlogits @ Wg, dWg = dlogits^T @ x.
+// =====================================================================================================================
+constexpr int GS_MAXE = 16;
+
+template <typename T>
+__global__ void __launch_bounds__(256) gate_small_fwd_kernel(const T* x, const T* wg, T* logits, int Tn, int D, int E) {
+  typedef typename Vec16<T>::V V;
+  constexpr int N = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int t = wave_g; t < Tn; t += nw) {
+    float acc[GS_MAXE];
+#pragma unroll
+    for (int e = 0; e < GS_MAXE; ++e) acc[e] = 0.f;
+    for (int d = lane * N; d < D; d += 64 * N) {
+      const V xv = *(const V*)(x + (int64_t)t * D + d);
+#pragma unroll
+      for (int e = 0; e < GS_MAXE; ++e) {
+        if (e < E) {
+          const V wv = *(const V*)(wg + (int64_t)e * D + d);
+#pragma unroll
+          for (int j = 0; j < N; ++j) acc[e] += (float)xv[j] * (float)wv[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < GS_MAXE; ++e)
+      if (e < E) {
+        const float sum = wave_sum(acc[e]);
+        if (lane == 0) DT<T>::st(logits + (int64_t)t * E + e, sum);
+      }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gate_small_dx_kernel(const T* dl, const T* wg, T* dx, int Tn, int D, int E) {
+  typedef typename Vec16<T>::V V;
+  constexpr int N = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int t = wave_g; t < Tn; t += nw) {
+    float g[GS_MAXE];
+#pragma unroll
+    for (int e = 0; e < GS_MAXE; ++e) g[e] = e < E ? DT<T>::ld(dl + (int64_t)t * E + e) : 0.f;
+    for (int d = lane * N; d < D; d += 64 * N) {
+      float o[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) o[j] = 0.f;
+#pragma unroll
+      for (int e = 0; e < GS_MAXE; ++e) {
+        if (e < E) {
+          const V wv = *(const V*)(wg + (int64_t)e * D + d);
+#pragma unroll
+          for (int j = 0; j < N; ++j) o[j] += g[e] * (float)wv[j];
+        }
+      }
+      V ov;
+#pragma unroll
+      for (int j = 0; j < N; ++j) ov[j] = (T)o[j];
+      *(V*)(dx + (int64_t)t * D + d) = ov;
+    }
+  }
+}
+
+// grid (ceil(D / (64*N)), nranges), block 64: a lane owns one 16-byte column chunk for all E experts over the rows of its range;
+// partial[range][e][D] fp32, reduced over the ranges by a column-sum launch (deterministic)
+template <typename T>
+__global__ void __launch_bounds__(64) gate_small_dw_kernel(const T* dl, const T* x, float* partial, int Tn, int D, int E, int rows_per) {
+  typedef typename Vec16<T>::V V;
+  constexpr int N = Vec16<T>::N;
+  const int d = (blockIdx.x * 64 + threadIdx.x) * N;
+  const int r0 = blockIdx.y * rows_per, r1 = min(Tn, r0 + rows_per);
+  float acc[GS_MAXE][N];
+#pragma unroll
+  for (int e = 0; e < GS_MAXE; ++e)
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[e][j] = 0.f;
+  if (d < D) {
+    for (int t = r0; t < r1; ++t) {
+      const V xv = *(const V*)(x + (int64_t)t * D + d);
+#pragma unroll
+      for (int e = 0; e < GS_MAXE; ++e) {
+        if (e < E) {
+          const float g = DT<T>::ld(dl + (int64_t)t * E + e);
+#pragma unroll
+          for (int j = 0; j < N; ++j) acc[e][j] += g * (float)xv[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < GS_MAXE; ++e)
+      if (e < E)
+#pragma unroll
+        for (int j = 0; j < N; ++j) partial[((int64_t)blockIdx.y * E + e) * D + d + j] = acc[e][j];
+  }
+}
+
+// =====================================================================================================================
 // Experts dealt to the 8 XCDs by row count for the persistent weight-gradient kernel: rank r (0 = most rows, ties by index) goes
 // to XCD (r % 8) in snake order; order[x * slots + k] = the k-th expert of XCD x (slots = ceil(E / 8)), -1 for an empty slot.
 // One workgroup; O(E^2 / 64) per lane.
@@ -899,5 +1001,48 @@ int k_pair_cosine_bwd(const void* y, const float* gscale, void* dy, int T, int K
 int k_expert_order(const int32_t* offsets, int E, int32_t* order, hipStream_t st) {
   hipLaunchKernelGGL(expert_order_kernel, dim3(1), dim3(256), 0, st, offsets, E, order);
   CSMOE_CHECK_LAUNCH("expert_order");
+  return CSMOE_OK;
+}
+
+bool k_gate_small_ok(int D, int E, int dtype, const void* a, const void* b) {
+  const int n = dtype == CSMOE_BF16 ? 8 : 4;
+  return E <= GS_MAXE && D % n == 0 && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0);
+}
+
+int k_gate_small_fwd(const void* x, const void* wg, void* logits, int T, int D, int E, int dtype, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  dim3 grid(stride_grid(T)), block(256);
+  if (dtype == CSMOE_BF16) hipLaunchKernelGGL((gate_small_fwd_kernel<bf16>), grid, block, 0, st, (const bf16*)x, (const bf16*)wg, (bf16*)logits, T, D, E);
+  else                     hipLaunchKernelGGL((gate_small_fwd_kernel<float>), grid, block, 0, st, (const float*)x, (const float*)wg, (float*)logits, T, D, E);
+  CSMOE_CHECK_LAUNCH("gate_logits(small E)");
+  return CSMOE_OK;
+}
+
+int k_gate_small_dx(const void* dl, const void* wg, void* dx, int T, int D, int E, int dtype, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  dim3 grid(stride_grid(T)), block(256);
+  if (dtype == CSMOE_BF16) hipLaunchKernelGGL((gate_small_dx_kernel<bf16>), grid, block, 0, st, (const bf16*)dl, (const bf16*)wg, (bf16*)dx, T, D, E);
+  else                     hipLaunchKernelGGL((gate_small_dx_kernel<float>), grid, block, 0, st, (const float*)dl, (const float*)wg, (float*)dx, T, D, E);
+  CSMOE_CHECK_LAUNCH("gate_bwd_dx");
+  return CSMOE_OK;
+}
+
+int k_gate_small_dw_ranges(int T, int D, int dtype) {
+  const int n = dtype == CSMOE_BF16 ? 8 : 4;
+  const int colgroups = (D + 64 * n - 1) / (64 * n);
+  int r = (2048 + colgroups - 1) / colgroups;        // ~2048 waves in flight
+  const int maxr = (T + 31) / 32;                    // at least 32 rows per range
+  if (r > maxr) r = maxr;
+  return r < 1 ? 1 : r;
+}
+
+int k_gate_small_dw(const void* dl, const void* x, float* partial, int T, int D, int E, int dtype, int nranges, hipStream_t st) {
+  if (T == 0 || nranges <= 0) return CSMOE_OK;
+  const int n = dtype == CSMOE_BF16 ? 8 : 4;
+  dim3 grid((D + 64 * n - 1) / (64 * n), nranges), block(64);
+  const int rows_per = (T + nranges - 1) / nranges;
+  if (dtype == CSMOE_BF16) hipLaunchKernelGGL((gate_small_dw_kernel<bf16>), grid, block, 0, st, (const bf16*)dl, (const bf16*)x, partial, T, D, E, rows_per);
+  else                     hipLaunchKernelGGL((gate_small_dw_kernel<float>), grid, block, 0, st, (const float*)dl, (const float*)x, partial, T, D, E, rows_per);
+  CSMOE_CHECK_LAUNCH("gate_bwd_dw");
   return CSMOE_OK;
 }

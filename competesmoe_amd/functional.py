@@ -102,10 +102,11 @@ class GateLogits(torch.autograd.Function):
         x2, wg = ctx.saved_tensors
         dlogits = dlogits.contiguous()
         dx = dw = None
+        small = ops.gate_bwd_small_ok(x2.shape[1], wg.shape[0], x2.dtype)      # few experts: row passes, not MFMA tiles
         if ctx.needs_input_grad[0]:
-            dx = ops.dense_gemm(dlogits, wg, L.B_KN)                   # [T,E] @ [E,D]
+            dx = ops.gate_bwd_dx(dlogits, wg) if small else ops.dense_gemm(dlogits, wg, L.B_KN)         # [T,E] @ [E,D]
         if ctx.needs_input_grad[1]:
-            dw = _chunked_dense_wgrad(dlogits, x2, ctx.w_dtype)        # [E,D] = dlogits^T x
+            dw = ops.gate_bwd_dw(dlogits, x2, ctx.w_dtype) if small else _chunked_dense_wgrad(dlogits, x2, ctx.w_dtype)
         return dx, dw
 
 
@@ -135,9 +136,10 @@ class LayerNormGate(torch.autograd.Function):
         dxn_gate = dwg = None
         if dlogits is not None:
             dlogits = dlogits.contiguous()
-            dxn_gate = ops.dense_gemm(dlogits, wg, L.B_KN)               # [T,E] @ [E,D]
+            small = ops.gate_bwd_small_ok(xn.shape[1], wg.shape[0], xn.dtype)
+            dxn_gate = ops.gate_bwd_dx(dlogits, wg) if small else ops.dense_gemm(dlogits, wg, L.B_KN)     # [T,E] @ [E,D]
             if ctx.needs_input_grad[4]:
-                dwg = _chunked_dense_wgrad(dlogits, xn, wd)
+                dwg = ops.gate_bwd_dw(dlogits, xn, wd) if small else _chunked_dense_wgrad(dlogits, xn, wd)
         a, b2 = dxn, dxn_gate
         if a is None:
             a, b2 = dxn_gate, None

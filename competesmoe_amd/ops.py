@@ -336,3 +336,30 @@ def pair_cosine_bwd(y3: torch.Tensor, gscale: torch.Tensor) -> torch.Tensor:
     with _timed("pair_cosine_bwd", 2 * T * K * D * y3.element_size()):
         L.check(lib.csmoe_pair_cosine_bwd(y3.data_ptr(), gscale.data_ptr(), dy.data_ptr(), T, K, D, _dt(y3), _stream()), "pair_cosine_bwd")
     return dy
+
+
+def gate_bwd_small_ok(D: int, E: int, dtype) -> bool:
+    return bool(lib.csmoe_gate_bwd_small_ok(D, E, L.BF16 if dtype == torch.bfloat16 else L.F32))
+
+
+def gate_bwd_dx(dlogits: torch.Tensor, w_gate: torch.Tensor) -> torch.Tensor:
+    T, E = dlogits.shape
+    D = w_gate.shape[1]
+    dx = torch.empty(T, D, dtype=dlogits.dtype, device=dlogits.device)
+    with _timed("gate_bwd_dx", T * D * dx.element_size()):
+        L.check(lib.csmoe_gate_bwd_dx(dlogits.data_ptr(), w_gate.data_ptr(), dx.data_ptr(), T, D, E, _dt(dlogits), _stream()), "gate_bwd_dx")
+    return dx
+
+
+def gate_bwd_dw(dlogits: torch.Tensor, x2: torch.Tensor, out_dtype) -> torch.Tensor:
+    T, E = dlogits.shape
+    D = x2.shape[1]
+    if T == 0:
+        return torch.zeros(E, D, dtype=out_dtype, device=x2.device)
+    nr = int(lib.csmoe_gate_bwd_dw_ranges(T, D, _dt(x2)))
+    part = torch.empty(nr, E * D, dtype=torch.float32, device=x2.device)
+    with _timed("gate_bwd_dw", T * D * x2.element_size()):
+        L.check(lib.csmoe_gate_bwd_dw(dlogits.data_ptr(), x2.data_ptr(), part.data_ptr(), T, D, E, _dt(x2), nr, _stream()), "gate_bwd_dw")
+    out = torch.empty(E * D, dtype=torch.float32, device=x2.device)
+    L.check(lib.csmoe_dense_colsum(part.data_ptr(), E * D, nr, E * D, out.data_ptr(), L.F32, L.F32, _stream()), "gate_bwd_dw sum")
+    return out.view(E, D).to(out_dtype)

@@ -160,6 +160,17 @@ int csmoe_grouped_colsum(const void* G, int64_t ldg, const int32_t* offsets, int
 
 int csmoe_dense_colsum(const void* G, int64_t ldg, int M, int N, void* out, int dtype, int out_dtype, csmoe_stream_t stream);
 
+/* Gate backward for few experts (E <= 16, D a multiple of 8 (bf16) / 4 (fp32), 16-byte aligned rows; csmoe_gate_bwd_small_ok):
+ * dx[T,D] = dlogits[T,E] @ w_gate[E,D] and the partial sums of dWg = dlogits^T @ x over csmoe_gate_bwd_dw_ranges(T, D, dtype)
+ * row ranges (partial [nranges][E][D] fp32; their sum over the ranges -- csmoe_dense_colsum over [nranges, E*D] -- is dWg).
+ * HBM-bound row passes replacing the MFMA GEMMs whose 128-wide tiles are empty at E = 4 (autograd of `self.gate(x)`, smoe.py:42;
+ * csmoe_gate_logits switches to the matching forward kernel by itself). */
+int csmoe_gate_bwd_small_ok(int D, int E, int dtype);
+int csmoe_gate_bwd_dx(const void* dlogits, const void* w_gate, void* dx, int T, int D, int E, int dtype, csmoe_stream_t stream);
+int csmoe_gate_bwd_dw_ranges(int T, int D, int dtype);
+int csmoe_gate_bwd_dw(const void* dlogits, const void* x, float* partial, int T, int D, int E, int dtype, int nranges,
+                      csmoe_stream_t stream);
+
 /* diversity loss of the competition step (moe.py:133-171, competesmoe.py:180-218): tok_loss[t] = sum over ordered pairs
  * i != j of <y[t,i,:] / max(|y[t,i,:]|, 1e-12), y[t,j,:] / ...> (fp32), y = [T, K, D] selected expert outputs, K <= 8; the loss
  * is sum_t tok_loss[t] / (T*K*K).  Backward: dy = gscale[0] * d(sum_t tok_loss)/dy in x.dtype (gscale: device scalar). */

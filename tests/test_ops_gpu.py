@@ -439,3 +439,25 @@ def test_wgrad_with_dealt_order_is_bit_identical():
 
 def rel_l2_(x, y):
     return float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------- skinny gate (few experts)
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,D,E", [(100, 64, 4), (12800, 1152, 4), (333, 4096, 8), (17, 200, 16), (50, 72, 1)])
+def test_gate_small_kernels(dt, T, D, E):
+    """gate logits / dx / dWg for E <= 16 (row-pass kernels) against fp32 torch products of the same x.dtype operands."""
+    if (dt == torch.bfloat16 and D % 8) or (dt == torch.float32 and D % 4):
+        pytest.skip("D not a multiple of the 16-byte chunk")
+    g = torch.Generator(device=DEV).manual_seed(T + E)
+    x = torch.randn(T, D, device=DEV, generator=g).to(dt)
+    wg = (torch.randn(E, D, device=DEV, generator=g) * 0.1).to(dt)
+    dl = torch.randn(T, E, device=DEV, generator=g).to(dt)
+    tol = 1e-5 if dt == torch.float32 else 2e-3
+    assert ops.gate_bwd_small_ok(D, E, dt)
+    lg = ops.gate_logits(x, wg)
+    assert rel_l2_(lg.float(), (x.float() @ wg.float().t()).to(dt).float()) <= tol
+    dx = ops.gate_bwd_dx(dl, wg)
+    assert rel_l2_(dx.float(), (dl.float() @ wg.float()).to(dt).float()) <= tol
+    dw = ops.gate_bwd_dw(dl, x, torch.float32)
+    assert rel_l2_(dw, dl.float().t() @ x.float()) <= (1e-5 if dt == torch.float32 else 1e-4)
+    assert not ops.gate_bwd_small_ok(D, 64, dt)
