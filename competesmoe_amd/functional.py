@@ -22,24 +22,40 @@ def _flip(layout: int) -> int:
 _CHUNK_OFFSETS = {}
 
 
-def _chunked_dense_wgrad(a: torch.Tensor, b: torch.Tensor, out_dtype) -> torch.Tensor:
+def _chunked_dense_wgrad(a: torch.Tensor, b: torch.Tensor, out_dtype, P: Optional[int] = None) -> torch.Tensor:
     """a^T b for a long, skinny reduction ([T,E]^T [T,D], T >> E): a single output tile row would occupy E*D/(128*128) CUs
     only, so the T rows are cut into chunks that the grouped weight-gradient kernel treats as pseudo-experts (fp32
     partials, deterministic), followed by one small sum."""
     T, Na = a.shape
     Nb = b.shape[1]
-    P = max(1, min(32, T // 1024))
+    if P is None:
+        P = max(1, min(32, T // 1024))
     if P == 1:
         return ops.dense_wgrad(a, b, out_dtype=out_dtype)
     key = (T, P, a.device)
     off = _CHUNK_OFFSETS.get(key)
     if off is None:
-        step = (T + P - 1) // P
+        step = ((T + P - 1) // P + 63) // 64 * 64          # whole K-tiles per chunk
         off = _CHUNK_OFFSETS[key] = torch.clamp(torch.arange(P + 1, dtype=torch.int64) * step, max=T).int().to(a.device)
     part = torch.empty(P, Na, Nb, dtype=torch.float32, device=a.device)
     ptrs = part.data_ptr() + torch.arange(P, device=a.device, dtype=torch.int64) * (Na * Nb * 4)
-    ops.grouped_wgrad(a, b, off, P, part, ptrs, tag="gate_wgrad")
+    ops.grouped_wgrad(a, b, off, P, part, ptrs, tag="gate_wgrad" if Na <= 64 else "grouped_wgrad_splitk")
+    if Na * Nb >= (1 << 20):      # big partials: the column-sum kernel streams them at HBM rate (torch's sum(0) does not)
+        return ops.dense_colsum(part.view(P, Na * Nb), out_dtype=torch.float32).view(Na, Nb).to(out_dtype)
     return part.sum(0).to(out_dtype)
+
+
+def _dense_wgrad(a: torch.Tensor, b: torch.Tensor, out_dtype) -> torch.Tensor:
+    """Weight gradient of ONE dense expert, a^T b with [M, Na]^T [M, Nb].  ceil(Na/256) * ceil(Nb/256) output tiles: 85 at the
+    reference's SigLIP shape (4304 x 1152) on a 256-CU chip -- then the reduction is split over row chunks (pseudo-experts of
+    the grouped kernel, fp32 partials, one small sum) until about two tiles per CU are in flight."""
+    M, Na = a.shape
+    Nb = b.shape[1]
+    tiles = ((Na + 255) // 256) * ((Nb + 255) // 256)
+    P = min(16, (512 + tiles - 1) // tiles, M // 1024)
+    if tiles >= 384 or P < 2:
+        return ops.dense_wgrad(a, b, out_dtype=out_dtype)
+    return _chunked_dense_wgrad(a, b, out_dtype, P=P)
 
 
 def _chunked_dense_colsum(g: torch.Tensor, out_dtype) -> torch.Tensor:
@@ -392,11 +408,11 @@ class DenseFFN(torch.autograd.Function):
         dh = ops.dense_gemm(dy, w2o, _flip(layout), epilogue=L.EPI_ACTGRAD, act=act, aux=hpre)
         gw1 = gb1 = gw2 = gb2 = dx = None
         if ctx.needs_input_grad[3]:
-            gw2 = ops.dense_wgrad(dy, hact, out_dtype=dt_w2) if layout == L.B_NK else ops.dense_wgrad(hact, dy, out_dtype=dt_w2)
+            gw2 = _dense_wgrad(dy, hact, dt_w2) if layout == L.B_NK else _dense_wgrad(hact, dy, dt_w2)
         if dt_b2 is not None and ctx.needs_input_grad[4]:
             gb2 = _chunked_dense_colsum(dy, dt_b2)
         if ctx.needs_input_grad[1]:
-            gw1 = ops.dense_wgrad(dh, x2, out_dtype=dt_w1) if layout == L.B_NK else ops.dense_wgrad(x2, dh, out_dtype=dt_w1)
+            gw1 = _dense_wgrad(dh, x2, dt_w1) if layout == L.B_NK else _dense_wgrad(x2, dh, dt_w1)
         if dt_b1 is not None and ctx.needs_input_grad[2]:
             gb1 = _chunked_dense_colsum(dh, dt_b1)
         if ctx.needs_input_grad[0]:
