@@ -217,25 +217,39 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dxn, 
       }
     }
   }
-  // four waves -> one partial row per workgroup
-  float* red = (float*)lds;                        // [4][2][D]
+  // four waves -> one partial row per workgroup, 1024 columns at a time (32 KiB of LDS: a [4][2][D] buffer would be 128 KiB at
+  // D = 4096 and leave ONE workgroup = four waves per CU for a kernel that lives on bytes in flight)
+  float* red = (float*)lds;                        // [4 waves][2][1024]
+  constexpr int GP = 1024 / (64 * N);              // chunk groups (64 chunks = 64 * N columns each) per pass
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) {
-    const int ci = c * 64 + lane;
-    if (ci < nch) {
+  for (int c0 = 0; c0 < CPL; c0 += GP) {
+    if (c0 * 64 * N < D) {                          // uniform
 #pragma unroll
-      for (int e = 0; e < N; ++e) {
-        red[(wave * 2 + 0) * D + ci * N + e] = dg[c][e];
-        red[(wave * 2 + 1) * D + ci * N + e] = db[c][e];
+      for (int cc = 0; cc < GP; ++cc) {
+        const int c = c0 + cc;
+        if (c < CPL) {
+          const int ci = c * 64 + lane;
+          if (ci < nch) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+              red[(wave * 2 + 0) * 1024 + (cc * 64 + lane) * N + e] = dg[c][e];
+              red[(wave * 2 + 1) * 1024 + (cc * 64 + lane) * N + e] = db[c][e];
+            }
+          }
+        }
       }
+      __syncthreads();
+      const int col0 = c0 * 64 * N;
+      for (int o = threadIdx.x; o < 2 * 1024; o += 256) {
+        const int which = o >> 10, cl = o & 1023;
+        if (col0 + cl < D) {
+          const float sum = (red[(0 * 2 + which) * 1024 + cl] + red[(1 * 2 + which) * 1024 + cl]) +
+                            (red[(2 * 2 + which) * 1024 + cl] + red[(3 * 2 + which) * 1024 + cl]);
+          partial[(int64_t)blockIdx.x * 2 * D + which * D + col0 + cl] = sum;
+        }
+      }
+      __syncthreads();
     }
-  }
-  __syncthreads();
-  for (int o = threadIdx.x; o < 2 * D; o += 256) {
-    const int which = o / D, col = o - which * D;
-    const float sum = (red[(0 * 2 + which) * D + col] + red[(1 * 2 + which) * D + col]) +
-                      (red[(2 * 2 + which) * D + col] + red[(3 * 2 + which) * D + col]);
-    partial[(int64_t)blockIdx.x * 2 * D + o] = sum;
   }
 }
 
@@ -266,14 +280,14 @@ int k_layernorm_fwd(const void* x, const void* gamma, const void* beta, float ep
 
 int k_layernorm_bwd_blocks(int T) {
   int nb = (T + 3) / 4;
-  return nb < 512 ? (nb < 1 ? 1 : nb) : 512;
+  return nb < 1024 ? (nb < 1 ? 1 : nb) : 1024;
 }
 
 template <typename T, int CPL, bool KEEP>
 int launch_ln_bwd(const void* dxn, const void* dxn2, const void* x, const void* gamma, const float* mean, const float* rstd, const void* add,
                   void* dx, float* partial, int Tn, int D, hipStream_t st) {
   dim3 grid(k_layernorm_bwd_blocks(Tn)), block(256);
-  const int bytes = 4 * 2 * D * 4;
+  const int bytes = 4 * 2 * 1024 * 4;
   int rc;
   if ((rc = raise_lds(ln_bwd_kernel<T, CPL, KEEP>, bytes, "layernorm_bwd"))) return rc;
   hipLaunchKernelGGL((ln_bwd_kernel<T, CPL, KEEP>), grid, block, bytes, st, (const T*)dxn, (const T*)dxn2, (const T*)x, (const T*)gamma, mean, rstd,
