@@ -12,13 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSMOE_LIB") or os.path.join(_HERE, "lib", "libcsmoe_hip.so")   # CSMOE_LIB: A/B builds only
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_SILU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4, 5
 SEL_SOFTMAX, SEL_RAW, SEL_TOPK_SOFTMAX, SEL_SIGMOID = 0, 1, 2, 3
 COMBINE_SEQ, COMBINE_DOT, COMBINE_SEQ_RW = 0, 1, 2
 B_NK, B_KN = 0, 1
 EPI_PLAIN, EPI_BIAS, EPI_BIAS_ACT, EPI_ACTGRAD = 0, 1, 2, 3
 
-ACT_CODES = {"none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU, "gelu_tanh": ACT_GELU_TANH, "silu": ACT_SILU}
+ACT_CODES = {"none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU, "gelu_tanh": ACT_GELU_TANH, "silu": ACT_SILU,
+             "quick_gelu": ACT_QUICK_GELU}
 
 _p, _i, _l = C.c_void_p, C.c_int, C.c_int64
 

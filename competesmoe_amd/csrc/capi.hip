@@ -204,7 +204,7 @@ int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, in
   CSMOE_CHECK_ARG(dtype_ok(dtype), "grouped_gemm: bad dtype %d", dtype);
   CSMOE_CHECK_ARG(E > 0 && M >= 0 && N > 0 && Kd > 0, "grouped_gemm: bad shape E=%d M=%d N=%d Kd=%d", E, M, N, Kd);
   CSMOE_CHECK_ARG(b_layout == CSMOE_B_NK || b_layout == CSMOE_B_KN, "grouped_gemm: bad B layout %d", b_layout);
-  CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && act >= 0 && act <= 4, "grouped_gemm: bad epilogue/act");
+  CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && act >= 0 && act <= 5, "grouped_gemm: bad epilogue/act");
   CSMOE_CHECK_ARG(b_ptrs && offsets && (M == 0 || (A && C)), "grouped_gemm: null pointer");
   CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "grouped_gemm: ACTGRAD epilogue needs aux");
   CSMOE_CHECK_ARG(lda >= Kd && ldc >= N && ldb >= (b_layout == CSMOE_B_NK ? Kd : N), "grouped_gemm: leading dimension too small");

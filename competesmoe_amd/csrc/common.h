@@ -61,6 +61,7 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
       return 0.5f * x * (1.f + tanhf(inner));
     }
     case CSMOE_ACT_SILU: return x / (1.f + __expf(-x));
+    case CSMOE_ACT_QUICK_GELU: return x / (1.f + __expf(-1.702f * x));
     default: return x;
   }
 }
@@ -85,8 +86,27 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
       float s = 1.f / (1.f + __expf(-x));
       return s * (1.f + x * (1.f - s));
     }
+    case CSMOE_ACT_QUICK_GELU: {
+      float s = 1.f / (1.f + __expf(-1.702f * x));
+      return s * (1.f + 1.702f * x * (1.f - s));
+    }
     default: return 1.f;
   }
+}
+
+// quick-GELU as the reference computes it on x.dtype tensors, `input * torch.sigmoid(1.702 * input)` (transformers
+// QuickGELUActivation): THREE elementwise ops, each rounding to x.dtype (the caller rounds the final product)
+template <typename T>
+__device__ __forceinline__ float quick_gelu_rounded(float x) {
+  const float t = DT<T>::rnd(1.702f * x);
+  const float s = DT<T>::rnd(1.f / (1.f + __expf(-t)));
+  return x * s;
+}
+template <typename T>
+__device__ __forceinline__ float quick_gelu_grad_rounded(float x) {
+  const float t = DT<T>::rnd(1.702f * x);
+  const float s = DT<T>::rnd(1.f / (1.f + __expf(-t)));
+  return s + 1.702f * x * s * (1.f - s);
 }
 
 // ------------------------------------------------------------------ wave reductions (64 lanes)

@@ -118,11 +118,12 @@ __global__ void __launch_bounds__(256) gg_generic_kernel(GGArgs p) {
       if (p.epilogue == CSMOE_EPI_ACTGRAD) {
         float g = DT<T>::rnd(v);
         float h = DT<T>::ld((const T*)p.aux + o);
-        DT<T>::st((T*)p.C + o, g * act_bwd(h, p.act));
+        DT<T>::st((T*)p.C + o, g * (p.act == CSMOE_ACT_QUICK_GELU ? quick_gelu_grad_rounded<T>(h) : act_bwd(h, p.act)));
       } else {
         float h = DT<T>::rnd(v + bias);
         DT<T>::st((T*)p.C + o, h);
-        if (p.epilogue == CSMOE_EPI_BIAS_ACT && p.C2) DT<T>::st((T*)p.C2 + o, act_fwd(h, p.act));
+        if (p.epilogue == CSMOE_EPI_BIAS_ACT && p.C2)
+          DT<T>::st((T*)p.C2 + o, p.act == CSMOE_ACT_QUICK_GELU ? quick_gelu_rounded<T>(h) : act_fwd(h, p.act));
       }
     }
   } else {

@@ -178,6 +178,10 @@ __device__ __forceinline__ void act_fwd8(float (&v)[8], int act) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_SILU);
       break;
+    case CSMOE_ACT_QUICK_GELU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = quick_gelu_rounded<bf16>(v[j]);
+      break;
     default: break;
   }
 }
@@ -199,6 +203,10 @@ __device__ __forceinline__ void act_bwd8(float (&h)[8], int act) {
     case CSMOE_ACT_SILU:
 #pragma unroll
       for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_SILU);
+      break;
+    case CSMOE_ACT_QUICK_GELU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = quick_gelu_grad_rounded<bf16>(h[j]);
       break;
     default:
 #pragma unroll

@@ -21,34 +21,29 @@ from ..functional import ExpertTable, GateLogits, MoEFFNModules, MoEFFNModulesRe
 from .. import ops
 
 
+_ACT_PROBE = torch.tensor([-30.0, -8.0, -4.0, -1.5, -0.3, 0.0, 0.4, 1.1, 3.0, 8.0, 30.0])
+_ACT_CACHE = {}
+
+
 def _act_code(mod) -> int:
-    """Map an activation module / callable to the kernel's activation code."""
-    name = type(mod).__name__.lower()
-    if isinstance(mod, nn.GELU):
-        return L.ACT_GELU_TANH if getattr(mod, "approximate", "none") == "tanh" else L.ACT_GELU
-    if isinstance(mod, nn.ReLU):
-        return L.ACT_RELU
-    if isinstance(mod, nn.SiLU):
-        return L.ACT_SILU
-    if isinstance(mod, nn.Identity):
-        return L.ACT_NONE
-    # transformers.activations classes (ACT2FN): GELUActivation, PytorchGELUTanh / GELUTanh, NewGELUActivation, SiLUActivation
-    if "tanh" in name or "newgelu" in name or "fastgelu" in name:
-        return L.ACT_GELU_TANH
-    if "gelu" in name:
-        return L.ACT_GELU
-    if "silu" in name or "swish" in name:
-        return L.ACT_SILU
-    if "relu" in name:
-        return L.ACT_RELU
-    fn = getattr(mod, "__name__", "")
-    if fn in ("gelu",):
-        return L.ACT_GELU
-    if fn in ("relu",):
-        return L.ACT_RELU
-    if fn in ("silu",):
-        return L.ACT_SILU
-    raise NotImplementedError(f"competesmoe_amd: unsupported expert activation {mod!r}")
+    """Map an activation module / callable to the kernel's activation code by what it COMPUTES (class names lie: transformers'
+    ACT2FN has GELUActivation, PytorchGELUTanh, NewGELUActivation, FastGELUActivation, QuickGELUActivation, ... and an `nn.Tanh`
+    must not be taken for a tanh-GELU): the callable is probed once on a few points and compared with the supported functions."""
+    key = id(type(mod)) if isinstance(mod, nn.Module) else id(mod)
+    hit = _ACT_CACHE.get((key, getattr(mod, "approximate", None)))
+    if hit is not None:
+        return hit
+    import torch.nn.functional as F
+    with torch.no_grad():
+        out = mod(_ACT_PROBE.clone()).float()
+    refs = ((L.ACT_RELU, F.relu(_ACT_PROBE)), (L.ACT_GELU, F.gelu(_ACT_PROBE)), (L.ACT_GELU_TANH, F.gelu(_ACT_PROBE, approximate="tanh")),
+            (L.ACT_SILU, F.silu(_ACT_PROBE)), (L.ACT_QUICK_GELU, _ACT_PROBE * torch.sigmoid(1.702 * _ACT_PROBE)), (L.ACT_NONE, _ACT_PROBE))
+    for code, ref in refs:
+        if out.shape == ref.shape and torch.allclose(out, ref, atol=2e-6, rtol=0):
+            _ACT_CACHE[(key, getattr(mod, "approximate", None))] = code
+            return code
+    raise NotImplementedError(f"competesmoe_amd: unsupported expert activation {mod!r} (supported: ReLU, GELU (erf / tanh), "
+                              "SiLU, quick-GELU, identity)")
 
 
 def parse_expert(expert: nn.Module) -> Tuple[nn.Linear, int, nn.Linear]:

@@ -26,7 +26,8 @@ extern "C" {
 typedef void* csmoe_stream_t;
 
 enum { CSMOE_F32 = 0, CSMOE_BF16 = 1 };
-enum { CSMOE_ACT_NONE = 0, CSMOE_ACT_RELU = 1, CSMOE_ACT_GELU = 2, CSMOE_ACT_GELU_TANH = 3, CSMOE_ACT_SILU = 4 };
+enum { CSMOE_ACT_NONE = 0, CSMOE_ACT_RELU = 1, CSMOE_ACT_GELU = 2, CSMOE_ACT_GELU_TANH = 3, CSMOE_ACT_SILU = 4,
+       CSMOE_ACT_QUICK_GELU = 5 /* x * sigmoid(1.702 x): CLIP towers (clip_smoe.py CLIPMLP, hidden_act "quick_gelu") */ };
 enum { CSMOE_OK = 0, CSMOE_ERR_INVALID = 1, CSMOE_ERR_LAUNCH = 2, CSMOE_ERR_UNSUPPORTED = 3 };
 
 /* Router selection rule (what top-k runs on, how the K weights are normalised). */

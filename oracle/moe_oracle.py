@@ -114,6 +114,7 @@ ACTS = {
     "gelu_tanh": lambda h: F.gelu(h, approximate="tanh"),
     "relu": lambda h: F.relu(h),
     "silu": lambda h: F.silu(h),
+    "quick_gelu": lambda h: h * torch.sigmoid(1.702 * h),      # transformers QuickGELUActivation (CLIP towers, clip_smoe.py CLIPMLP)
     "none": lambda h: h,
 }
 

@@ -107,3 +107,44 @@ def test_empty_batch(dt):
     out.sum().backward()                                       # nothing to route: all parameter grads are zero / absent
     for p in layer.experts.parameters():
         assert p.grad is None or float(p.grad.abs().sum()) == 0.0
+
+
+class QuickGELU(nn.Module):                     # what transformers' ACT2FN["quick_gelu"] computes (CLIP towers)
+    def forward(self, x):
+        return x * torch.sigmoid(1.702 * x)
+
+
+class CLIPMLPLike(nn.Module):
+    def __init__(self, D, F):
+        super().__init__()
+        self.activation_fn = QuickGELU()
+        self.fc1, self.fc2 = nn.Linear(D, F), nn.Linear(F, D)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_quick_gelu_experts_and_unknown_activations(dt):
+    """CLIP-style experts (fc1 / quick-GELU / fc2) against the oracle; activations are recognised by what they compute, so an
+    nn.Tanh or a LeakyReLU is refused instead of being taken for a GELU / ReLU by its name."""
+    D, F, E, K = 64, 96, 4, 2
+    torch.manual_seed(0)
+    experts = nn.ModuleList([CLIPMLPLike(D, F) for _ in range(E)])
+    layer = get_moe("smoe")(D, D, E, K, experts, ARGS).to(dt)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 40, D, generator=g).to(dt)
+    ex = [tuple(p.detach().clone() for p in (m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)) for m in layer.experts]
+    with torch.no_grad():
+        o_out, _, _, st = O.llava_smoe_forward(x, layer.gate.weight.detach().clone(), ex, "quick_gelu", K, ARGS)
+    layer = layer.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    out = layer(xg)[0]
+    out.float().sum().backward()
+    with torch.no_grad():
+        idx = layer.topk_expert(layer.gate_logits(x.to(DEV)))[1].cpu().long()
+    same = (idx == st["selected_experts"]).all(-1).reshape(-1)          # bf16 logits: near-ties may route a row differently
+    assert same.float().mean() >= 0.95
+    assert rel_l2(out.detach().cpu().reshape(-1, D)[same], o_out.reshape(-1, D)[same]) <= (2e-5 if dt == torch.float32 else 2e-3)
+    assert torch.isfinite(xg.grad).all() and float(layer.experts[0].fc1.weight.grad.abs().sum()) > 0
+    for bad in (nn.Tanh(), nn.LeakyReLU(0.1), nn.ReLU6()):
+        e2 = nn.ModuleList([nn.Sequential(nn.Linear(D, F), bad, nn.Linear(F, D)) for _ in range(E)])
+        with pytest.raises(NotImplementedError):
+            get_moe("smoe")(D, D, E, K, e2, ARGS).to(DEV)(x.float().to(DEV))
