@@ -163,6 +163,8 @@ class MoeLayer(nn.Module):
         has_b2 = all(b is not None for b in b2)
         if (not has_b1 and any(b is not None for b in b1)) or (not has_b2 and any(b is not None for b in b2)):
             raise NotImplementedError("competesmoe_amd: experts must all have (or all lack) a bias")
+        if any(w.shape != w1[0].shape for w in w1) or any(w.shape != w2[0].shape for w in w2) or w2[0].shape[1] != w1[0].shape[0]:
+            raise NotImplementedError("competesmoe_amd: all experts of a layer must have the same Linear shapes (fc1 [F,D], fc2 [Dout,F])")
         params = w1 + (b1 if has_b1 else []) + w2 + (b2 if has_b2 else [])
         for p in params:
             if p.dtype != dtype or p.device != device or not p.is_contiguous():
