@@ -261,7 +261,7 @@ int csmoe_gate_bwd_small_ok(int D, int E, int dtype) { return dtype_ok(dtype) &&
 
 int csmoe_gate_bwd_dx(const void* dlogits, const void* w_gate, void* dx, int T, int D, int E, int dtype, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && T >= 0 && D > 0 && E > 0, "gate_bwd_dx: bad arguments");
-  CSMOE_CHECK_ARG(k_gate_small_ok(D, E, dtype, w_gate, dx), "gate_bwd_dx: needs E <= 16, D a multiple of the 16-byte chunk, aligned operands");
+  CSMOE_CHECK_ARG(k_gate_small_ok(D, E, dtype, w_gate, dx), "gate_bwd_dx: needs E <= 4, D a multiple of the 16-byte chunk, aligned operands");
   CSMOE_CHECK_ARG(T == 0 || (dlogits && w_gate && dx), "gate_bwd_dx: null pointer");
   return k_gate_small_dx(dlogits, w_gate, dx, T, D, E, dtype, (hipStream_t)stream);
 }
@@ -271,7 +271,7 @@ int csmoe_gate_bwd_dw_ranges(int T, int D, int dtype) { return dtype_ok(dtype) &
 int csmoe_gate_bwd_dw(const void* dlogits, const void* x, float* partial, int T, int D, int E, int dtype, int nranges,
                       csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && T >= 0 && D > 0 && E > 0 && nranges > 0, "gate_bwd_dw: bad arguments");
-  CSMOE_CHECK_ARG(k_gate_small_ok(D, E, dtype, x, nullptr), "gate_bwd_dw: needs E <= 16, D a multiple of the 16-byte chunk, aligned operands");
+  CSMOE_CHECK_ARG(k_gate_small_ok(D, E, dtype, x, nullptr), "gate_bwd_dw: needs E <= 4, D a multiple of the 16-byte chunk, aligned operands");
   CSMOE_CHECK_ARG(T == 0 || (dlogits && x && partial), "gate_bwd_dw: null pointer");
   return k_gate_small_dw(dlogits, x, partial, T, D, E, dtype, nranges, (hipStream_t)stream);
 }

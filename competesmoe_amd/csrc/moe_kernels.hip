@@ -616,8 +616,10 @@ __global__ void __launch_bounds__(256) softplus_mean_bwd_kernel(const T* y, cons
 // =====================================================================================================================
 constexpr int PC_MAXK = 8;
 
-template <typename T, bool BWD>
+template <typename T, bool BWD, bool VEC>
 __global__ void __launch_bounds__(256) pair_cosine_kernel(const T* y, float* tok_loss, const float* gscale, T* dy, int Tn, int K, int D) {
+  typedef typename Vec16<T>::V V;
+  constexpr int N = VEC ? Vec16<T>::N : 1;         // elements per lane and step (16-byte accesses when VEC)
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
@@ -628,15 +630,31 @@ __global__ void __launch_bounds__(256) pair_cosine_kernel(const T* y, float* tok
     for (int i = 0; i < PC_MAXK; ++i)
 #pragma unroll
       for (int j = 0; j < PC_MAXK; ++j) dot[i][j] = 0.f;
-    for (int d = lane; d < D; d += 64) {
-      float v[PC_MAXK];
+    for (int d = lane * N; d < D; d += 64 * N) {
+      float v[PC_MAXK][N];
 #pragma unroll
-      for (int i = 0; i < PC_MAXK; ++i) v[i] = i < K ? DT<T>::ld(base + (int64_t)i * D + d) : 0.f;
+      for (int i = 0; i < PC_MAXK; ++i) {
+        if (i < K) {
+          if constexpr (VEC) {
+            const V x = *(const V*)(base + (int64_t)i * D + d);
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[i][e] = (float)x[e];
+          } else {
+            v[i][0] = DT<T>::ld(base + (int64_t)i * D + d);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < N; ++e) v[i][e] = 0.f;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < PC_MAXK; ++i)
 #pragma unroll
         for (int j = i; j < PC_MAXK; ++j)
-          if (j < K) dot[i][j] += v[i] * v[j];
+          if (j < K) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) dot[i][j] += v[i][e] * v[j][e];
+          }
     }
     float inv[PC_MAXK];
 #pragma unroll
@@ -666,13 +684,36 @@ __global__ void __launch_bounds__(256) pair_cosine_kernel(const T* y, float* tok
           if (j < K && j != k) ns[k] += (j > k ? dot[k][j] : dot[j][k]) * inv[k] * inv[j];
       }
       T* dbase = dy + (int64_t)t * K * D;
-      for (int d = lane; d < D; d += 64) {
-        float n[PC_MAXK], tot = 0.f;
+      for (int d = lane * N; d < D; d += 64 * N) {
+        float n[PC_MAXK][N], tot[N];
 #pragma unroll
-        for (int i = 0; i < PC_MAXK; ++i) { n[i] = i < K ? DT<T>::ld(base + (int64_t)i * D + d) * inv[i] : 0.f; tot += n[i]; }
+        for (int e = 0; e < N; ++e) tot[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < PC_MAXK; ++i) {
+          if (i < K) {
+            if constexpr (VEC) {
+              const V x = *(const V*)(base + (int64_t)i * D + d);
+#pragma unroll
+              for (int e = 0; e < N; ++e) n[i][e] = (float)x[e] * inv[i];
+            } else {
+              n[i][0] = DT<T>::ld(base + (int64_t)i * D + d) * inv[i];
+            }
+#pragma unroll
+            for (int e = 0; e < N; ++e) tot[e] += n[i][e];
+          }
+        }
 #pragma unroll
         for (int k = 0; k < PC_MAXK; ++k)
-          if (k < K) DT<T>::st(dbase + (int64_t)k * D + d, g2 * inv[k] * ((tot - n[k]) - ns[k] * n[k]));
+          if (k < K) {
+            if constexpr (VEC) {
+              V o;
+#pragma unroll
+              for (int e = 0; e < N; ++e) o[e] = (T)(g2 * inv[k] * ((tot[e] - n[k][e]) - ns[k] * n[k][e]));
+              *(V*)(dbase + (int64_t)k * D + d) = o;
+            } else {
+              DT<T>::st(dbase + (int64_t)k * D + d, g2 * inv[k] * ((tot[0] - n[k][0]) - ns[k] * n[k][0]));
+            }
+          }
       }
     }
   }
@@ -983,8 +1024,14 @@ int k_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, voi
 int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st) {
   if (T == 0) return CSMOE_OK;
   dim3 grid(stride_grid(T)), block(256);
-  if (dtype == CSMOE_BF16) hipLaunchKernelGGL((pair_cosine_kernel<bf16, false>), grid, block, 0, st, (const bf16*)y, tok_loss, (const float*)nullptr, (bf16*)nullptr, T, K, D);
-  else                     hipLaunchKernelGGL((pair_cosine_kernel<float, false>), grid, block, 0, st, (const float*)y, tok_loss, (const float*)nullptr, (float*)nullptr, T, K, D);
+  const bool vec = ((uintptr_t)y & 15) == 0 && D % (dtype == CSMOE_BF16 ? 8 : 4) == 0;
+  if (dtype == CSMOE_BF16) {
+    if (vec) hipLaunchKernelGGL((pair_cosine_kernel<bf16, false, true>), grid, block, 0, st, (const bf16*)y, tok_loss, (const float*)nullptr, (bf16*)nullptr, T, K, D);
+    else     hipLaunchKernelGGL((pair_cosine_kernel<bf16, false, false>), grid, block, 0, st, (const bf16*)y, tok_loss, (const float*)nullptr, (bf16*)nullptr, T, K, D);
+  } else {
+    if (vec) hipLaunchKernelGGL((pair_cosine_kernel<float, false, true>), grid, block, 0, st, (const float*)y, tok_loss, (const float*)nullptr, (float*)nullptr, T, K, D);
+    else     hipLaunchKernelGGL((pair_cosine_kernel<float, false, false>), grid, block, 0, st, (const float*)y, tok_loss, (const float*)nullptr, (float*)nullptr, T, K, D);
+  }
   CSMOE_CHECK_LAUNCH("pair_cosine");
   return CSMOE_OK;
 }
@@ -992,8 +1039,14 @@ int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype
 int k_pair_cosine_bwd(const void* y, const float* gscale, void* dy, int T, int K, int D, int dtype, hipStream_t st) {
   if (T == 0) return CSMOE_OK;
   dim3 grid(stride_grid(T)), block(256);
-  if (dtype == CSMOE_BF16) hipLaunchKernelGGL((pair_cosine_kernel<bf16, true>), grid, block, 0, st, (const bf16*)y, (float*)nullptr, gscale, (bf16*)dy, T, K, D);
-  else                     hipLaunchKernelGGL((pair_cosine_kernel<float, true>), grid, block, 0, st, (const float*)y, (float*)nullptr, gscale, (float*)dy, T, K, D);
+  const bool vec = ((((uintptr_t)y | (uintptr_t)dy) & 15) == 0) && D % (dtype == CSMOE_BF16 ? 8 : 4) == 0;
+  if (dtype == CSMOE_BF16) {
+    if (vec) hipLaunchKernelGGL((pair_cosine_kernel<bf16, true, true>), grid, block, 0, st, (const bf16*)y, (float*)nullptr, gscale, (bf16*)dy, T, K, D);
+    else     hipLaunchKernelGGL((pair_cosine_kernel<bf16, true, false>), grid, block, 0, st, (const bf16*)y, (float*)nullptr, gscale, (bf16*)dy, T, K, D);
+  } else {
+    if (vec) hipLaunchKernelGGL((pair_cosine_kernel<float, true, true>), grid, block, 0, st, (const float*)y, (float*)nullptr, gscale, (float*)dy, T, K, D);
+    else     hipLaunchKernelGGL((pair_cosine_kernel<float, true, false>), grid, block, 0, st, (const float*)y, (float*)nullptr, gscale, (float*)dy, T, K, D);
+  }
   CSMOE_CHECK_LAUNCH("pair_cosine_bwd");
   return CSMOE_OK;
 }
@@ -1006,7 +1059,9 @@ int k_expert_order(const int32_t* offsets, int E, int32_t* order, hipStream_t st
 
 bool k_gate_small_ok(int D, int E, int dtype, const void* a, const void* b) {
   const int n = dtype == CSMOE_BF16 ? 8 : 4;
-  return E <= GS_MAXE && D % n == 0 && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0);
+  // E <= 4 only: the row passes are VALU work proportional to E (0.22 ms at E = 8, D = 4096, T = 32768 against 0.09 ms for the
+  // MFMA path), they win where the GEMM tiles are nearly empty (0.024 vs 0.09 ms at the reference's E = 4, D = 1152)
+  return E <= 4 && D % n == 0 && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0);
 }
 
 int k_gate_small_fwd(const void* x, const void* wg, void* logits, int T, int D, int E, int dtype, hipStream_t st) {

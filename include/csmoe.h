@@ -161,7 +161,7 @@ int csmoe_grouped_colsum(const void* G, int64_t ldg, const int32_t* offsets, int
 
 int csmoe_dense_colsum(const void* G, int64_t ldg, int M, int N, void* out, int dtype, int out_dtype, csmoe_stream_t stream);
 
-/* Gate backward for few experts (E <= 16, D a multiple of 8 (bf16) / 4 (fp32), 16-byte aligned rows; csmoe_gate_bwd_small_ok):
+/* Gate backward for few experts (E <= 4, D a multiple of 8 (bf16) / 4 (fp32), 16-byte aligned rows; csmoe_gate_bwd_small_ok):
  * dx[T,D] = dlogits[T,E] @ w_gate[E,D] and the partial sums of dWg = dlogits^T @ x over csmoe_gate_bwd_dw_ranges(T, D, dtype)
  * row ranges (partial [nranges][E][D] fp32; their sum over the ranges -- csmoe_dense_colsum over [nranges, E*D] -- is dWg).
  * HBM-bound row passes replacing the MFMA GEMMs whose 128-wide tiles are empty at E = 4 (autograd of `self.gate(x)`, smoe.py:42;

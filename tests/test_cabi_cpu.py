@@ -39,3 +39,11 @@ def test_argument_validation_without_gpu():
         _lib.check(rc, "router_select")
     rc = _lib.lib.csmoe_grouped_gemm(None, 8, None, 0, 8, None, None, 0, 4, 8, 8, None, None, None, 8, 0, 0, 1, 0, None)
     assert rc == 1
+
+
+def test_library_has_no_undefined_symbols():
+    """dlopen with RTLD_NOW: an internal symbol that is declared but not defined must fail HERE, not at the first call on the GPU
+    box (lazy binding hides it on the build container)."""
+    import ctypes
+    from competesmoe_amd import _lib
+    ctypes.CDLL(_lib.LIB_PATH, mode=ctypes.RTLD_GLOBAL | 2)      # 2 = RTLD_NOW

@@ -443,9 +443,9 @@ def rel_l2_(x, y):
 
 # ---------------------------------------------------------------------------------------------------- skinny gate (few experts)
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("T,D,E", [(100, 64, 4), (12800, 1152, 4), (333, 4096, 8), (17, 200, 16), (50, 72, 1)])
+@pytest.mark.parametrize("T,D,E", [(100, 64, 4), (12800, 1152, 4), (333, 4096, 3), (17, 200, 2), (50, 72, 1)])
 def test_gate_small_kernels(dt, T, D, E):
-    """gate logits / dx / dWg for E <= 16 (row-pass kernels) against fp32 torch products of the same x.dtype operands."""
+    """gate logits / dx / dWg for E <= 4 (row-pass kernels) against fp32 torch products of the same x.dtype operands."""
     if (dt == torch.bfloat16 and D % 8) or (dt == torch.float32 and D % 4):
         pytest.skip("D not a multiple of the 16-byte chunk")
     g = torch.Generator(device=DEV).manual_seed(T + E)
