@@ -119,7 +119,7 @@ class EPFFN(torch.autograd.Function):
             es = torch.tensor([], dtype=pd).element_size()
 
             def table(buf):
-                return buf.data_ptr() + torch.arange(E, device=dev, dtype=torch.int64) * (buf[0].numel() * es)
+                return ops.ptr_table(buf, E, buf[0].numel() * es)
 
             gW2 = torch.empty(E, tab.Dout, tab.F, dtype=pd, device=dev)
             ops.grouped_wgrad(dys, hact, lb.offsets, E, gW2, table(gW2), xcd_order=lb.xcd_order)

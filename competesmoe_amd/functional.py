@@ -38,7 +38,7 @@ def _chunked_dense_wgrad(a: torch.Tensor, b: torch.Tensor, out_dtype, P: Optiona
         step = ((T + P - 1) // P + 63) // 64 * 64          # whole K-tiles per chunk
         off = _CHUNK_OFFSETS[key] = torch.clamp(torch.arange(P + 1, dtype=torch.int64) * step, max=T).int().to(a.device)
     part = torch.empty(P, Na, Nb, dtype=torch.float32, device=a.device)
-    ptrs = part.data_ptr() + torch.arange(P, device=a.device, dtype=torch.int64) * (Na * Nb * 4)
+    ptrs = ops.ptr_table(part, P, Na * Nb * 4)
     ops.grouped_wgrad(a, b, off, P, part, ptrs, tag="gate_wgrad" if Na <= 64 else "grouped_wgrad_splitk")
     if Na * Nb >= (1 << 20):      # big partials: the column-sum kernel streams them at HBM rate (torch's sum(0) does not)
         return ops.dense_colsum(part.view(P, Na * Nb), out_dtype=torch.float32).view(Na, Nb).to(out_dtype)
@@ -72,7 +72,7 @@ def _chunked_dense_colsum(g: torch.Tensor, out_dtype) -> torch.Tensor:
         step = (M + P - 1) // P
         off = _CHUNK_OFFSETS[key] = torch.clamp(torch.arange(P + 1, dtype=torch.int64) * step, max=M).int().to(g.device)
     part = torch.empty(P, N, dtype=torch.float32, device=g.device)
-    ptrs = part.data_ptr() + torch.arange(P, device=g.device, dtype=torch.int64) * (N * 4)
+    ptrs = ops.ptr_table(part, P, N * 4)
     ops.grouped_colsum(g, off, P, part, ptrs)
     return part.sum(0).to(out_dtype)
 
@@ -87,15 +87,15 @@ def _grouped_colsum(g: torch.Tensor, offsets: torch.Tensor, E: int, pd) -> torch
     if wgs >= 256 or g.shape[0] < 4096:
         out = torch.empty(E, N, dtype=pd, device=dev)
         es = out.element_size()
-        ops.grouped_colsum(g, offsets, E, out, out.data_ptr() + torch.arange(E, device=dev, dtype=torch.int64) * (N * es))
+        ops.grouped_colsum(g, offsets, E, out, ops.ptr_table(out, E, N * es))
         return out
     P = min(64, max(2, 512 // wgs))
     cnt = (offsets[1:] - offsets[:-1]).long()
-    j = torch.arange(P, device=dev, dtype=torch.int64)
+    j = ops.cached_arange(P, dev)
     starts = offsets[:-1, None].long() + (cnt[:, None] * j[None, :]) // P             # [E, P]; chunk (e, j) ends where (e, j+1) starts
     chunk_off = torch.cat([starts.reshape(-1), offsets[-1:].long()]).int()
     part = torch.empty(E * P, N, dtype=torch.float32, device=dev)
-    ops.grouped_colsum(g, chunk_off, E * P, part, part.data_ptr() + torch.arange(E * P, device=dev, dtype=torch.int64) * (N * 4))
+    ops.grouped_colsum(g, chunk_off, E * P, part, ops.ptr_table(part, E * P, N * 4))
     return part.view(E, P, N).sum(1).to(pd)
 
 
@@ -244,7 +244,7 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
 
         def table(buf):
             stride = buf[0].numel() * es
-            return buf.data_ptr() + torch.arange(E, device=dev, dtype=torch.int64) * stride
+            return ops.ptr_table(buf, E, stride)
 
         if tab.layout == L.B_NK:
             gW2 = torch.empty(E, tab.Dout, tab.F, dtype=pd, device=dev)
@@ -345,7 +345,7 @@ class MoEFFNPacked(torch.autograd.Function):
         k_op = keys.contiguous() if keys.dtype == op else keys.to(op)
         v_op = values.contiguous() if values.dtype == op else values.to(op)
         es = k_op.element_size()
-        ar = torch.arange(E, device=dev, dtype=torch.int64)
+        ar = ops.cached_arange(E, dev)
         b_op = None
         b1 = None
         if bias is not None:

@@ -105,7 +105,7 @@ class MoeLayer(nn.Module):
         density_1_proxy = gate_softmax.mean(dim=-2)
         # F.one_hot range-checks its input with .item() (a device sync that drains the launch queue): compare instead
         top1 = selected_experts[..., 0].long().unsqueeze(-1)
-        one_hot = (top1 == torch.arange(E, device=top1.device)).float()
+        one_hot = (top1 == ops.cached_arange(E, top1.device)).float()
         density_1 = one_hot.mean(dim=-2)
         return (density_1_proxy * density_1).mean() * float(E ** 2)
 

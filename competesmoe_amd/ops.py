@@ -127,6 +127,31 @@ class Bins:
         return self._xcd_order
 
 
+_STRIDE_TABLES = {}
+
+
+def ptr_table(buf: torch.Tensor, n: int, stride_bytes: int) -> torch.Tensor:
+    """Device table of n pointers buf.data_ptr() + i * stride_bytes.  The i * stride part is cached per (n, stride, device), so a
+    table costs ONE tiny add kernel per call instead of arange + mul + add (the backward builds four of them per step, and at the
+    reference's small LLaVA shapes a step is bound by the number of launches)."""
+    key = (n, stride_bytes, buf.device)
+    offs = _STRIDE_TABLES.get(key)
+    if offs is None:
+        offs = _STRIDE_TABLES[key] = torch.arange(n, device=buf.device, dtype=torch.int64) * stride_bytes
+    return offs + buf.data_ptr()
+
+
+_ARANGES = {}
+
+
+def cached_arange(n: int, device, dtype=torch.int64) -> torch.Tensor:
+    key = (n, torch.device(device), dtype)
+    t = _ARANGES.get(key)
+    if t is None:
+        t = _ARANGES[key] = torch.arange(n, device=device, dtype=dtype)
+    return t
+
+
 def bin_tokens(idx: torch.Tensor, E: int) -> Bins:
     _need_cuda(idx)
     if idx.dtype != torch.int32:

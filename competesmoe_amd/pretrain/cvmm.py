@@ -47,7 +47,7 @@ class _CVMM(torch.autograd.Function):
         E, Din, Dout = keys.shape
         xf = x.reshape(-1, x.shape[-1]).to(op).contiguous()
         k_op = keys.to(op).contiguous()
-        ar = torch.arange(E, device=x.device, dtype=torch.int64)
+        ar = ops.cached_arange(E, x.device)
         ptrs = k_op.data_ptr() + ar * (Din * Dout * k_op.element_size())
         if rows_are_slots:      # x has one row per (token, k) slot in flat order -> bring to the binned order
             xs = ops.dispatch_rows(xf, ops.Bins(None, None, bins.perm, None, bins.n, bins.E, 1))
@@ -76,7 +76,7 @@ class _CVMM(torch.autograd.Function):
         else:
             gs = ops.dispatch_rows(g, ops.Bins(None, None, bins.perm, None, bins.n, bins.E, 1))
         gk = torch.empty(E, Din, Dout, dtype=kd, device=g.device)
-        ar = torch.arange(E, device=g.device, dtype=torch.int64)
+        ar = ops.cached_arange(E, g.device)
         ops.grouped_wgrad(xs, gs, bins.offsets, E, gk, gk.data_ptr() + ar * (Din * Dout * gk.element_size()))
         dxs = ops.grouped_gemm(gs, ptrs, L.B_NK, Dout, Din, bins.offsets, E)
         if rows_are_slots:

@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib as L
+from .. import ops
 from ..functional import DenseFFN, GateLogits, MoEFFNPacked, RouterSelect
 from .framework_layers import LoggingLayer, OncePerIterLayer, RegularizedLayer
 
@@ -153,7 +154,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         E = self.num_of_experts
         proxy = gate_softmax.mean(dim=-2)
         top1 = selected_experts[..., 0].long().unsqueeze(-1)
-        dens = (top1 == torch.arange(E, device=top1.device)).float().mean(dim=-2)      # no F.one_hot: it syncs the device
+        dens = (top1 == ops.cached_arange(E, top1.device)).float().mean(dim=-2)      # no F.one_hot: it syncs the device
         return (proxy * dens).mean() * float(E ** 2)
 
     # ------------------------------------------------------------------ eval-time statistics (moe.py:163-182)
