@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--block", action="store_true", help="time the block around the layer, x + MoE(LayerNorm(x)) (SURVEY.md section 8 f1), with the fused LayerNorm+gate / residual-combine kernels")
     ap.add_argument("--block-unfused", action="store_true", help="same block composed from torch LayerNorm, the plain layer and a torch add (A/B for --block)")
     ap.add_argument("--stack", default="llava", choices=["llava", "pretrain"], help="pretrain: the LM-pretrain stack's `smoe` layer (packed fp32 master weights keys/values, ReLU, no bias, bf16 autocast: the cvmm path) instead of the LLaVA-stack layer")
+    ap.add_argument("--ep-chunks", type=int, default=0, help="expert-parallel runs: groups of local experts whose all-to-all overlaps the grouped GEMMs (competesmoe_amd.ep); 0 = pick the fastest of 1 / 2 / 4 in a short untimed trial before the warmup (1 with a single rank)")
     ap.add_argument("--force-ep", action="store_true", help="use the expert-parallel layer even with one rank (smoke-tests the N>1 code path)")
     return ap.parse_args()
 
@@ -208,6 +209,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ep_tune = None
+    if world > 1 or a.force_ep:
+        if a.ep_chunks > 0 or world == 1:
+            layer.chunks = max(1, a.ep_chunks)
+        else:   # untimed trial: overlap depth that is fastest on THIS node (max over ranks, so every rank picks the same)
+            ep_tune = {}
+            for c in (1, 2, 4):
+                if c > a.experts // world:
+                    continue
+                layer.chunks = c
+                step()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                fence()
+                tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ep_tune[c] = round(float(tt) / 3 * 1e3, 3)
+            layer.chunks = min(ep_tune, key=ep_tune.get)
     for _ in range(a.warmup):
         step()
     fence()
@@ -267,7 +288,8 @@ def main():
                                    f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, Linear+bias/GELU experts, "
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
                        "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
-                       "parallelism": "single GPU" if world == 1 else f"ep{world} (experts sharded, RCCL all-to-all)"},
+                       "parallelism": "single GPU" if world == 1 else f"ep{world} (experts sharded, RCCL all-to-all)",
+                       **({"ep_chunks": layer.chunks, "ep_chunks_trial_ms": ep_tune} if (world > 1 or a.force_ep) else {})},
             "roofline": roof, "kernels": detail,
         }
         if world == 1 and not a.no_cpu_baseline:

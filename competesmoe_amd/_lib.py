@@ -47,6 +47,9 @@ SIGNATURES = {
     "csmoe_dense_colsum": (_i, [_p, _l, _i, _i, _p, _i, _i, _p]),
     "csmoe_softplus_mean": (_i, [_p, _p, _i, _i, _i, _p]),
     "csmoe_softplus_mean_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "csmoe_router_aux_workspace_floats": (_l, [_i, _i, _i]),
+    "csmoe_router_aux": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "csmoe_router_aux_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "csmoe_gate_bwd_small_ok": (_i, [_i, _i, _i]),
     "csmoe_gate_bwd_dx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "csmoe_gate_bwd_dw_ranges": (_i, [_i, _i, _i]),

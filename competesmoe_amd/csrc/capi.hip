@@ -41,6 +41,11 @@ int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, 
 int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
 int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st);
 int k_expert_order(const int32_t* offsets, int E, int32_t* order, hipStream_t st);
+int64_t k_router_aux_workspace_floats(int B, int N, int E);
+int k_router_aux_fwd(const void* logits, const float* sm, const int32_t* idx, float* lse, float* partial, float* dens, float* out2,
+                     int B, int N, int E, int K, int dtype, hipStream_t st);
+int k_router_aux_bwd(const float* sm, const float* dens, const float* lse, const float* g_bal, const float* g_z, float* dsm,
+                     void* dlogits, int B, int N, int E, int dtype, hipStream_t st);
 bool k_gate_small_ok(int D, int E, int dtype, const void* a, const void* b);
 int k_gate_small_fwd(const void* x, const void* wg, void* logits, int T, int D, int E, int dtype, hipStream_t st);
 int k_gate_small_dx(const void* dl, const void* wg, void* dx, int T, int D, int E, int dtype, hipStream_t st);
@@ -255,6 +260,22 @@ int csmoe_grouped_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, 
     return gg_fast_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, out_dtype, accumulate, 0, nullptr, st);
   }
   return gg_generic_wgrad(A, lda, B, ldb, offsets, E, Na, Nb, c_ptrs, ldc, dtype, out_dtype, accumulate, 0, nullptr, st);
+}
+
+int64_t csmoe_router_aux_workspace_floats(int B, int N, int E) { return (B > 0 && N > 0 && E > 0) ? k_router_aux_workspace_floats(B, N, E) : 0; }
+
+int csmoe_router_aux(const void* logits, const float* softmax, const int32_t* idx, float* lse, float* workspace, float* dens,
+                     float* out2, int B, int N, int E, int K, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && B > 0 && N > 0 && E > 0 && E <= 1024 && K > 0, "router_aux: bad arguments (E <= 1024)");
+  CSMOE_CHECK_ARG(softmax && idx && workspace && dens && out2 && (logits == nullptr || lse), "router_aux: null pointer");
+  return k_router_aux_fwd(logits, softmax, idx, lse, workspace, dens, out2, B, N, E, K, dtype, (hipStream_t)stream);
+}
+
+int csmoe_router_aux_bwd(const float* softmax, const float* dens, const float* lse, const float* g_balance, const float* g_z,
+                         float* dsoftmax, void* dlogits, int B, int N, int E, int dtype, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && B > 0 && N > 0 && E > 0, "router_aux_bwd: bad arguments");
+  CSMOE_CHECK_ARG(softmax && dens && (dsoftmax || dlogits) && (!dlogits || (lse && g_z)) && (!dsoftmax || g_balance), "router_aux_bwd: null pointer");
+  return k_router_aux_bwd(softmax, dens, lse, g_balance, g_z, dsoftmax, dlogits, B, N, E, dtype, (hipStream_t)stream);
 }
 
 int csmoe_gate_bwd_small_ok(int D, int E, int dtype) { return dtype_ok(dtype) && D > 0 && E > 0 && k_gate_small_ok(D, E, dtype, nullptr, nullptr) ? 1 : 0; }

@@ -822,6 +822,124 @@ __global__ void __launch_bounds__(64) gate_small_dw_kernel(const T* dl, const T*
 }
 
 // =====================================================================================================================
+// Router auxiliary losses of the LLaVA stack in two launches (+ one for the backward) instead of ~35 tiny tensor ops:
+//   balance (moe.py:90-110) = mean_{b,e}( mean_n softmax[b,n,e] * mean_n [idx[b,n,0] == e] ) * E^2          (fp32)
+//   z-loss  (moe.py:71-88)  = mean_t( logsumexp(logits[t,:])^2 ), evaluated on x.dtype tensors like the reference: the
+//                             logsumexp, its square and the mean are each rounded to x.dtype
+// logsumexp(logits[t]) = logits[t,i1] - log(softmax[t,i1]) with i1 the top-1 expert (softmax is the fp32 softmax of the same
+// logits, so no second reduction over E is needed).  Deterministic: per-workgroup partial rows, then one reducing workgroup.
+// =====================================================================================================================
+constexpr int RA_MAXQ = 4;                        // E <= 1024: up to 4 column chunks of 256
+
+// Tokens per workgroup: about 512 workgroups over the chip, at least 32 tokens each.
+static inline int ra_chunk(int B, int N) {
+  const int64_t T = (int64_t)B * N;
+  int c = (int)((T + 511) / 512);
+  c = (c + 31) / 32 * 32;
+  return c < 32 ? 32 : c;
+}
+
+// threads = (row r, column col): cols = 2^lc columns (E rounded up to a power of two, at most 256) x 256/cols token rows, so that
+// consecutive lanes read consecutive experts of consecutive tokens (coalesced for any E, no idle lanes at E = 4).
+template <typename T>
+__global__ void __launch_bounds__(256) router_aux_partial_kernel(const T* logits, const float* sm, const int32_t* idx, float* lse_out,
+                                                                 float* partial, int N, int E, int K, int nchunk, int chunk, int lc) {
+  __shared__ float red[2][RA_MAXQ][256];
+  __shared__ float zred[256];
+  const int b = blockIdx.x / nchunk, c = blockIdx.x % nchunk;
+  const int tid = threadIdx.x, cols = 1 << lc, rows = 256 >> lc;
+  const int col = tid & (cols - 1), r = tid >> lc;
+  const int n0 = c * chunk, n1 = min(N, n0 + chunk);
+  float px[RA_MAXQ], dn[RA_MAXQ], zs = 0.f;
+#pragma unroll
+  for (int q = 0; q < RA_MAXQ; ++q) { px[q] = 0.f; dn[q] = 0.f; }
+  for (int n = n0 + r; n < n1; n += rows) {
+    const int64_t t = (int64_t)b * N + n;
+    const int i1 = idx[t * K];
+#pragma unroll
+    for (int q = 0; q < RA_MAXQ; ++q) {
+      const int e = q * cols + col;
+      if (e < E) {
+        px[q] += sm[t * E + e];
+        dn[q] += (e == i1) ? 1.f : 0.f;
+      }
+    }
+    if (logits && col == 0) {
+      const float l = DT<T>::rnd(DT<T>::ld(logits + t * E + i1) - __logf(sm[t * E + i1]));
+      lse_out[t] = l;
+      zs += DT<T>::rnd(l * l);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RA_MAXQ; ++q) { red[0][q][tid] = px[q]; red[1][q][tid] = dn[q]; }
+  zred[tid] = zs;
+  __syncthreads();
+  float* out = partial + (int64_t)blockIdx.x * (2 * E + 1);
+  for (int o = tid; o < 2 * E + 1; o += 256) {
+    float acc = 0.f;
+    if (o < 2 * E) {
+      const int which = o >= E ? 1 : 0, e = o - which * E;
+      const int q = e >> lc, cl = e & (cols - 1);
+      for (int rr = 0; rr < rows; ++rr) acc += red[which][q][(rr << lc) + cl];
+    } else {
+      for (int rr = 0; rr < rows; ++rr) acc += zred[rr << lc];
+    }
+    out[o] = acc;
+  }
+}
+
+// one workgroup: partial rows -> dens[b,e] (kept for the backward), balance, z
+template <typename T>
+__global__ void __launch_bounds__(256) router_aux_final_kernel(const float* partial, float* dens, float* out2, int B, int N, int E,
+                                                               int nchunk, int has_z) {
+  __shared__ float acc[256];
+  float bal = 0.f, z = 0.f;
+  for (int o = threadIdx.x; o < B * E; o += 256) {
+    const int b = o / E, e = o - b * E;
+    float p = 0.f, d = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+      const float* row = partial + (int64_t)(b * nchunk + c) * (2 * E + 1);
+      p += row[e];
+      d += row[E + e];
+    }
+    p /= (float)N;
+    d /= (float)N;
+    dens[o] = d;
+    bal += p * d;
+  }
+  if (has_z)
+    for (int o = threadIdx.x; o < B * nchunk; o += 256) z += partial[(int64_t)o * (2 * E + 1) + 2 * E];
+  acc[threadIdx.x] = bal;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) acc[threadIdx.x] += acc[threadIdx.x + st]; __syncthreads(); }
+  const float bal_tot = acc[0];
+  __syncthreads();
+  acc[threadIdx.x] = z;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) acc[threadIdx.x] += acc[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    out2[0] = bal_tot / (float)(B * E) * (float)E * (float)E;
+    out2[1] = has_z ? DT<T>::rnd(acc[0] / (float)((int64_t)B * N)) : 0.f;
+  }
+}
+
+// dsoftmax[t,e] = g_bal * E^2 / (B*E) * dens[b,e] / N   (fp32);   dlogits[t,e] = g_z * 2 * lse[t] / T * softmax[t,e]   (x.dtype)
+template <typename T>
+__global__ void __launch_bounds__(256) router_aux_bwd_kernel(const float* sm, const float* dens, const float* lse, const float* g_bal,
+                                                             const float* g_z, float* dsm, T* dlogits, int B, int N, int E) {
+  const int64_t total = (int64_t)B * N * E;
+  const float kb = g_bal ? g_bal[0] * (float)E / (float)B / (float)N : 0.f;
+  const float kz = (g_z && dlogits) ? g_z[0] * 2.f / (float)((int64_t)B * N) : 0.f;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int64_t t = o / E;
+    const int e = (int)(o - t * E);
+    const int b = (int)(t / N);
+    if (dsm) dsm[o] = kb * dens[b * E + e];
+    if (dlogits) DT<T>::st(dlogits + o, kz * lse[t] * sm[o]);
+  }
+}
+
+// =====================================================================================================================
 // Experts dealt to the 8 XCDs by row count for the persistent weight-gradient kernel: rank r (0 = most rows, ties by index) goes
 // to XCD (r % 8) in snake order; order[x * slots + k] = the k-th expert of XCD x (slots = ceil(E / 8)), -1 for an empty slot.
 // One workgroup; O(E^2 / 64) per lane.
@@ -1099,5 +1217,37 @@ int k_gate_small_dw(const void* dl, const void* x, float* partial, int T, int D,
   if (dtype == CSMOE_BF16) hipLaunchKernelGGL((gate_small_dw_kernel<bf16>), grid, block, 0, st, (const bf16*)dl, (const bf16*)x, partial, T, D, E, rows_per);
   else                     hipLaunchKernelGGL((gate_small_dw_kernel<float>), grid, block, 0, st, (const float*)dl, (const float*)x, partial, T, D, E, rows_per);
   CSMOE_CHECK_LAUNCH("gate_bwd_dw");
+  return CSMOE_OK;
+}
+
+int64_t k_router_aux_workspace_floats(int B, int N, int E) {
+  const int chunk = ra_chunk(B, N), nchunk = (N + chunk - 1) / chunk;
+  return (int64_t)B * nchunk * (2 * E + 1);
+}
+
+int k_router_aux_fwd(const void* logits, const float* sm, const int32_t* idx, float* lse, float* partial, float* dens, float* out2,
+                     int B, int N, int E, int K, int dtype, hipStream_t st) {
+  const int chunk = ra_chunk(B, N), nchunk = (N + chunk - 1) / chunk;
+  int lc = 1;
+  while ((1 << lc) < E && lc < 8) ++lc;
+  dim3 grid(B * nchunk), block(256);
+  if (dtype == CSMOE_BF16) {
+    hipLaunchKernelGGL((router_aux_partial_kernel<bf16>), grid, block, 0, st, (const bf16*)logits, sm, idx, lse, partial, N, E, K, nchunk, chunk, lc);
+    hipLaunchKernelGGL((router_aux_final_kernel<bf16>), dim3(1), block, 0, st, partial, dens, out2, B, N, E, nchunk, logits ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL((router_aux_partial_kernel<float>), grid, block, 0, st, (const float*)logits, sm, idx, lse, partial, N, E, K, nchunk, chunk, lc);
+    hipLaunchKernelGGL((router_aux_final_kernel<float>), dim3(1), block, 0, st, partial, dens, out2, B, N, E, nchunk, logits ? 1 : 0);
+  }
+  CSMOE_CHECK_LAUNCH("router_aux_fwd");
+  return CSMOE_OK;
+}
+
+int k_router_aux_bwd(const float* sm, const float* dens, const float* lse, const float* g_bal, const float* g_z, float* dsm,
+                     void* dlogits, int B, int N, int E, int dtype, hipStream_t st) {
+  const int64_t total = (int64_t)B * N * E;
+  dim3 grid((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), block(256);
+  if (dtype == CSMOE_BF16) hipLaunchKernelGGL((router_aux_bwd_kernel<bf16>), grid, block, 0, st, sm, dens, lse, g_bal, g_z, dsm, (bf16*)dlogits, B, N, E);
+  else                     hipLaunchKernelGGL((router_aux_bwd_kernel<float>), grid, block, 0, st, sm, dens, lse, g_bal, g_z, dsm, (float*)dlogits, B, N, E);
+  CSMOE_CHECK_LAUNCH("router_aux_bwd");
   return CSMOE_OK;
 }

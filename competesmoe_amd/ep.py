@@ -13,11 +13,18 @@ collective API wants host split sizes), then rows out, rows back; backward mirro
 Received rows arrive grouped by source rank; a second (local, K=1) binning pass regroups them by local expert for the
 grouped GEMM and is undone before the return trip.
 
+Overlap (`chunks` > 1): the local experts are cut into `chunks` groups.  A group's rows are P contiguous sub-slices of the binned
+row space (one per peer), exchanged as one asynchronous all-to-all that torch's RCCL process group runs on its own HIP stream:
+all outbound exchanges are queued at once, the grouped GEMMs of group c start as soon as ITS rows are in, and its results travel
+back while group c+1 is in the GEMMs.  Exposed communication drops from 2 (4 in the backward) full exchanges to about 1/chunks of
+them.  chunks = 1 is the plain path (one blocking all_to_all_single each way).
+
 Everything that touches `torch.distributed` is in the small functions at the top so the plumbing is testable with `gloo`
 on CPU (tests/test_ep_gloo.py); the compute between the exchanges is the same HIP kernels as the single-GPU path.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -41,10 +48,13 @@ class EPPlan:
     recv_splits: List[int]        # rows this rank receives from each peer
     recv_counts: torch.Tensor     # [P, E_local] int32 (device): rows from peer s for local expert e
     R: int                        # total rows received
+    send_host: Optional[torch.Tensor] = None     # [P, E_local] int64 (host) rows sent to peer p for ITS local expert e
+    recv_host: Optional[torch.Tensor] = None     # [P, E_local] int64 (host) copy of recv_counts
 
 
-def make_plan(counts: torch.Tensor, group=None) -> EPPlan:
-    """counts[E] (int32, device) = rows per GLOBAL expert on this rank -> exchange plan.  One small all-to-all + one host read."""
+def make_plan(counts: torch.Tensor, group=None, per_expert: bool = False) -> EPPlan:
+    """counts[E] (int32, device) = rows per GLOBAL expert on this rank -> exchange plan.  One small all-to-all + one host read
+    (2*P ints, or the two [P, E/P] count matrices when the chunked exchange needs per-expert sizes)."""
     P = dist.get_world_size(group)
     E = counts.numel()
     assert E % P == 0, "experts must divide evenly over the expert-parallel ranks"
@@ -52,6 +62,10 @@ def make_plan(counts: torch.Tensor, group=None) -> EPPlan:
     send = counts.view(P, El).contiguous()
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
+    if per_expert:
+        both = torch.stack([send, recv]).cpu().long()         # the one device->host sync of the exchange
+        sh, rh = both[0], both[1]
+        return EPPlan(P, El, sh.sum(1).tolist(), rh.sum(1).tolist(), recv, int(rh.sum()), sh, rh)
     both = torch.stack([send.sum(1), recv.sum(1)]).cpu()       # the one device->host sync of the exchange
     send_splits = [int(v) for v in both[0]]
     recv_splits = [int(v) for v in both[1]]
@@ -66,11 +80,78 @@ def a2a_rows(rows: torch.Tensor, in_splits: List[int], out_splits: List[int], gr
     return out
 
 
-def local_expert_ids(plan: EPPlan) -> torch.Tensor:
-    """Local expert id of every received row (rows arrive grouped by source rank, sorted by expert inside a group)."""
+class _Done:
+    def wait(self):
+        return True
+
+
+def exchange_views(outs: List[torch.Tensor], ins: List[torch.Tensor], group=None):
+    """Asynchronous all-to-all over per-peer row VIEWS (peer p gets ins[p], outs[p] is filled by peer p); returns a handle whose
+    wait() orders the current stream after the exchange.  RCCL: `dist.all_to_all(async_op=True)` -- grouped send/recv on the
+    process group's own HIP stream, started once the work already queued on the current stream is done.  Other backends (gloo in
+    the CPU tests) have no list all-to-all: the views are packed and exchanged with all_to_all_single, synchronously."""
+    if dist.get_backend(group) == "nccl":
+        return dist.all_to_all(outs, ins, group=group, async_op=True)
+    packed = torch.cat(ins) if len(ins) > 1 else ins[0].contiguous()
+    got = torch.empty(sum(o.shape[0] for o in outs), packed.shape[1], dtype=packed.dtype, device=packed.device)
+    dist.all_to_all_single(got, packed, output_split_sizes=[o.shape[0] for o in outs], input_split_sizes=[i.shape[0] for i in ins],
+                           group=group)
+    r = 0
+    for o in outs:
+        o.copy_(got[r:r + o.shape[0]])
+        r += o.shape[0]
+    return _Done()
+
+
+@dataclass
+class EPChunk:
+    """One group of local experts [e0, e1) of the chunked exchange."""
+    e0: int
+    e1: int
+    send_lo: List[int]            # per peer p: first row, in the binned row space, of the rows for p's local experts [e0, e1)
+    send_n: List[int]             # per peer p: their number
+    recv_n: List[int]             # per source s: rows arriving for my local experts [e0, e1)
+    R: int                        # sum(recv_n)
+
+
+def chunk_plan(plan: EPPlan, chunks: int) -> List[EPChunk]:
+    """Cut the local experts into `chunks` nearly equal groups and derive every group's send sub-slices / receive sizes (host)."""
+    P, El = plan.P, plan.E_local
+    C = max(1, min(chunks, El))
+    sh, rh = plan.send_host, plan.recv_host
+    goff = torch.zeros(P * El + 1, dtype=torch.int64)
+    goff[1:] = sh.flatten().cumsum(0)                         # offsets of the GLOBAL experts in the binned row space
+    out = []
+    for c in range(C):
+        e0, e1 = c * El // C, (c + 1) * El // C
+        lo = [int(goff[p * El + e0]) for p in range(P)]
+        n = [int(goff[p * El + e1]) - lo[p] for p in range(P)]
+        rn = [int(v) for v in rh[:, e0:e1].sum(1)]
+        out.append(EPChunk(e0, e1, lo, n, rn, sum(rn)))
+    return out
+
+
+def _views(buf: torch.Tensor, lo: List[int], n: List[int]) -> List[torch.Tensor]:
+    return [buf[a:a + k] for a, k in zip(lo, n)]
+
+
+def _packed_views(buf: torch.Tensor, n: List[int]) -> List[torch.Tensor]:
+    out, r = [], 0
+    for k in n:
+        out.append(buf[r:r + k])
+        r += k
+    return out
+
+
+def local_expert_ids(plan: EPPlan, e0: int = 0, e1: Optional[int] = None) -> torch.Tensor:
+    """Local expert id (relative to e0) of every received row of the experts [e0, e1) (rows arrive grouped by source rank, sorted
+    by expert inside a group)."""
     dev = plan.recv_counts.device
-    pattern = torch.arange(plan.E_local, device=dev, dtype=torch.int32).repeat(plan.P)
-    return torch.repeat_interleave(pattern, plan.recv_counts.flatten().long(), output_size=plan.R)
+    e1 = plan.E_local if e1 is None else e1
+    pattern = torch.arange(e1 - e0, device=dev, dtype=torch.int32).repeat(plan.P)
+    cnt = plan.recv_counts[:, e0:e1]
+    R = plan.R if (e0 == 0 and e1 == plan.E_local) else int(plan.recv_host[:, e0:e1].sum())
+    return torch.repeat_interleave(pattern, cnt.flatten().long(), output_size=R)
 
 
 # ------------------------------------------------------------------------------------------------ the EP FFN
@@ -144,6 +225,118 @@ class EPFFN(torch.autograd.Function):
         return (dx2, dw, None, None, None, None, None, *pg)
 
 
+class EPFFNChunked(torch.autograd.Function):
+    """EPFFN with the exchanges cut into groups of local experts and overlapped with the grouped GEMMs (module docstring).
+    Same numbers as EPFFN: every row goes through the same kernels with the same operands, only the launch grouping differs."""
+
+    @staticmethod
+    def forward(ctx, x2, w, idx, tab: ExpertTable, E_global: int, group, combine_mode: int, chunks: int, *params):
+        x2 = x2.contiguous()
+        T = x2.shape[0]
+        bins = ops.bin_tokens(idx, E_global)
+        xs = ops.dispatch_tokens(x2, bins)
+        plan = make_plan(bins.counts, group, per_expert=True)
+        cps = chunk_plan(plan, chunks)
+        recvs, works = [], []
+        for cp in cps:                                   # every outbound exchange is queued now, on the process group's stream
+            r = torch.empty(cp.R, xs.shape[1], dtype=xs.dtype, device=xs.device)
+            works.append(exchange_views(_packed_views(r, cp.recv_n), _views(xs, cp.send_lo, cp.send_n), group))
+            recvs.append(r)
+        y = torch.empty(bins.n, tab.Dout, dtype=xs.dtype, device=xs.device)
+        back, keep, saved = [], [], []
+        for cp, r, wk in zip(cps, recvs, works):
+            with ops._timed("ep_wait_exposed"):
+                wk.wait()
+            Ec = cp.e1 - cp.e0
+            lb = ops.bin_tokens(local_expert_ids(plan, cp.e0, cp.e1).view(-1, 1), Ec)
+            rs = ops.dispatch_rows(r, lb)
+            hpre, hact = ops.grouped_gemm(rs, tab.w1_ptrs[cp.e0:cp.e1], tab.layout, tab.D, tab.F, lb.offsets, Ec,
+                                          bias_ptrs=None if tab.b1_ptrs is None else tab.b1_ptrs[cp.e0:cp.e1],
+                                          epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True)
+            ys = ops.grouped_gemm(hact, tab.w2_ptrs[cp.e0:cp.e1], tab.layout, tab.F, tab.Dout, lb.offsets, Ec,
+                                  bias_ptrs=None if tab.b2_ptrs is None else tab.b2_ptrs[cp.e0:cp.e1],
+                                  epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
+            ret = ops.dispatch_rows(ys, _Unsort(lb))
+            back.append(exchange_views(_views(y, cp.send_lo, cp.send_n), _packed_views(ret, cp.recv_n), group))
+            keep.append(ret)                             # alive until the return trip has been waited for
+            saved.append((lb, rs, hpre, hact))
+        with ops._timed("ep_wait_exposed"):
+            for wk in back:
+                wk.wait()
+        del keep, recvs
+        out = ops.combine(y, bins, idx, w, combine_mode, T)
+        ctx.saved = (bins, plan, cps, saved, y)
+        ctx.tab, ctx.w, ctx.group, ctx.n_params = tab, w, group, len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        bins, plan, cps, saved, y = ctx.saved
+        ctx.saved = None
+        tab, group = ctx.tab, ctx.group
+        assert tab.layout == L.B_NK
+        E, dev, pd = tab.E, dout.device, tab.param_dtype
+        T = dout.shape[0]
+        need_params = any(ctx.needs_input_grad[8:])
+        need_dx = ctx.needs_input_grad[0]
+        dy, dw = ops.combine_bwd(dout.contiguous(), y, bins, ctx.w, want_dw=ctx.needs_input_grad[1])
+        recvs, works = [], []
+        for cp in cps:
+            r = torch.empty(cp.R, dy.shape[1], dtype=dy.dtype, device=dev)
+            works.append(exchange_views(_packed_views(r, cp.recv_n), _views(dy, cp.send_lo, cp.send_n), group))
+            recvs.append(r)
+        gW1 = gW2 = gb1 = gb2 = None
+        if need_params:
+            es = torch.tensor([], dtype=pd).element_size()
+
+            def table(buf):
+                return ops.ptr_table(buf, E, buf[0].numel() * es)
+
+            gW2 = torch.empty(E, tab.Dout, tab.F, dtype=pd, device=dev)
+            gW1 = torch.empty(E, tab.F, tab.D, dtype=pd, device=dev)
+            tW2, tW1 = table(gW2), table(gW1)
+            if tab.b1_ptrs is not None:
+                gb1 = torch.empty(E, tab.F, dtype=pd, device=dev)
+                tb1 = table(gb1)
+            if tab.b2_ptrs is not None:
+                gb2 = torch.empty(E, tab.Dout, dtype=pd, device=dev)
+                tb2 = table(gb2)
+        dxs = torch.empty(bins.n, tab.D, dtype=dy.dtype, device=dev) if need_dx else None
+        back, keep = [], []
+        for cp, r, wk, (lb, rs, hpre, hact) in zip(cps, recvs, works, saved):
+            with ops._timed("ep_wait_exposed"):
+                wk.wait()
+            e0, e1 = cp.e0, cp.e1
+            Ec = e1 - e0
+            dys = ops.dispatch_rows(r, lb)
+            dh = ops.grouped_gemm(dys, tab.w2_ptrs[e0:e1], L.B_KN, tab.F, tab.F, lb.offsets, Ec, epilogue=L.EPI_ACTGRAD, act=tab.act,
+                                  aux=hpre)
+            if need_dx:                                  # input gradient first: its return trip overlaps this group's weight gradients
+                dxs_s = ops.grouped_gemm(dh, tab.w1_ptrs[e0:e1], L.B_KN, tab.D, tab.D, lb.offsets, Ec)
+                ret = ops.dispatch_rows(dxs_s, _Unsort(lb))
+                back.append(exchange_views(_views(dxs, cp.send_lo, cp.send_n), _packed_views(ret, cp.recv_n), group))
+                keep.append(ret)
+            if need_params:
+                ops.grouped_wgrad(dys, hact, lb.offsets, Ec, gW2, tW2[e0:e1], xcd_order=lb.xcd_order)
+                ops.grouped_wgrad(dh, rs, lb.offsets, Ec, gW1, tW1[e0:e1], xcd_order=lb.xcd_order)
+                if gb1 is not None:
+                    ops.grouped_colsum(dh, lb.offsets, Ec, gb1, tb1[e0:e1])
+                if gb2 is not None:
+                    ops.grouped_colsum(dys, lb.offsets, Ec, gb2, tb2[e0:e1])
+        pg = [None] * ctx.n_params
+        if need_params:
+            seq = [gW1] + ([gb1] if gb1 is not None else []) + [gW2] + ([gb2] if gb2 is not None else [])
+            pg = [g[e] for g in seq for e in range(E)]
+        dx2 = None
+        if need_dx:
+            with ops._timed("ep_wait_exposed"):
+                for wk in back:
+                    wk.wait()
+            del keep
+            dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
+        return (dx2, dw, None, None, None, None, None, None, *pg)
+
+
 # ------------------------------------------------------------------------------------------------ module
 @register_moe("smoe_ep")
 class EPSMoeLayer(MoeLayer):
@@ -151,11 +344,13 @@ class EPSMoeLayer(MoeLayer):
     with this rank's E/P local experts (global ids rank*E/P ...).  The gate is replicated: its gradient is summed over the
     group after backward (tokens are data-parallel); expert gradients are local by construction."""
 
-    def __init__(self, in_embed_dim=768, out_embed_dim=768, num_of_experts=4, num_selected=2, expert=None, args=None, group=None):
+    def __init__(self, in_embed_dim=768, out_embed_dim=768, num_of_experts=4, num_selected=2, expert=None, args=None, group=None,
+                 chunks: Optional[int] = None):
         if not isinstance(expert, nn.ModuleList):
             raise ValueError("EPSMoeLayer: pass this rank's local experts as an nn.ModuleList")
         super().__init__(in_embed_dim, out_embed_dim, num_of_experts, num_selected, expert, args)
         self.group = group
+        self.chunks = chunks        # groups of local experts whose exchanges overlap the GEMMs; None: CSMOE_EP_CHUNKS, else 2 (1 at P=1)
         self.init_gate_weights()
         self.gate.weight.register_post_accumulate_grad_hook(self._sync_gate_grad)
 
@@ -163,14 +358,25 @@ class EPSMoeLayer(MoeLayer):
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(p.grad, group=self.group)
 
+    def _n_chunks(self) -> int:
+        c = self.chunks
+        if c is None:
+            env = os.environ.get("CSMOE_EP_CHUNKS")
+            c = int(env) if env else (2 if dist.get_world_size(self.group) > 1 else 1)
+        return max(1, min(int(c), len(self.experts)))
+
     def forward(self, x, return_id_experts=False, is_vision=False):
         B, N, D = x.shape
         gate_logits = self.gate_logits(x)
         weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
         tab, params = self._expert_table(len(self.experts), x.dtype, x.device)
-        out = EPFFN.apply(x.reshape(B * N, D), weights.reshape(B * N, weights.shape[-1]).contiguous(),
-                          selected_experts.reshape(B * N, selected_experts.shape[-1]).contiguous(), tab, self.num_of_experts, self.group,
-                          L.COMBINE_SEQ, *params)
+        chunks = self._n_chunks()
+        w2 = weights.reshape(B * N, weights.shape[-1]).contiguous()
+        i2 = selected_experts.reshape(B * N, selected_experts.shape[-1]).contiguous()
+        if chunks > 1:
+            out = EPFFNChunked.apply(x.reshape(B * N, D), w2, i2, tab, self.num_of_experts, self.group, L.COMBINE_SEQ, chunks, *params)
+        else:
+            out = EPFFN.apply(x.reshape(B * N, D), w2, i2, tab, self.num_of_experts, self.group, L.COMBINE_SEQ, *params)
         output = out.view(B, N, out.shape[-1])
         auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
         infor_aux = {}

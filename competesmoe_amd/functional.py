@@ -194,6 +194,33 @@ class RouterSelect(torch.autograd.Function):
         return ds, None, None, None
 
 
+class RouterAux(torch.autograd.Function):
+    """(balance loss fp32, z-loss in logits.dtype) of the LLaVA stack in two launches, one for the backward --
+    `balanceloss` (moe_model/model/moe/moe.py:90-110: mean_n softmax x mean_n one_hot(top-1), mean over (b, e), x E^2) and
+    `zloss` (moe.py:71-88: mean(logsumexp(logits)^2) evaluated in logits.dtype).  `sm` must be the fp32 softmax of `logits` and
+    idx[..., 0] its arg-max (what `topk_expert` returns); logits = None gives the balance loss alone (z = 0)."""
+
+    @staticmethod
+    def forward(ctx, logits, sm, idx):
+        sm = sm.contiguous()
+        idx = idx.contiguous()
+        if logits is not None:
+            logits = logits.contiguous()
+        out2, dens, lse = ops.router_aux(logits, sm, idx)
+        ctx.save_for_backward(sm, dens, lse)
+        ctx.ldtype = None if logits is None else logits.dtype
+        z = out2[1] if logits is None or logits.dtype == torch.float32 else out2[1].to(logits.dtype)
+        return out2[0], z
+
+    @staticmethod
+    def backward(ctx, g_bal, g_z):
+        sm, dens, lse = ctx.saved_tensors
+        gb = g_bal.float().reshape(1) if (g_bal is not None and ctx.needs_input_grad[1]) else None
+        gz = g_z.float().reshape(1) if (g_z is not None and ctx.ldtype is not None and ctx.needs_input_grad[0]) else None
+        dsm, dlogits = ops.router_aux_bwd(sm, dens, lse, gb, gz, ctx.ldtype or torch.float32)
+        return dlogits, dsm, None
+
+
 # ======================================================================================================== expert FFN
 @dataclass
 class ExpertTable:

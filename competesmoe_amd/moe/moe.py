@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
-from ..functional import ExpertTable, GateLogits, MoEFFNModules, MoEFFNModulesResidual, RouterSelect, DenseFFN, DiversityLoss
+from ..functional import (ExpertTable, GateLogits, MoEFFNModules, MoEFFNModulesResidual, RouterSelect, DenseFFN, DiversityLoss,
+                          RouterAux)
 from .. import ops
 
 
@@ -101,6 +102,8 @@ class MoeLayer(nn.Module):
         return torch.square(torch.logsumexp(gate_logits, dim=-1)).mean()
 
     def balanceloss(self, selected_experts, gate_softmax):
+        if self._fusable(selected_experts, gate_softmax):
+            return RouterAux.apply(None, gate_softmax, selected_experts)[0]
         E = gate_softmax.shape[-1]
         density_1_proxy = gate_softmax.mean(dim=-2)
         # F.one_hot range-checks its input with .item() (a device sync that drains the launch queue): compare instead
@@ -109,7 +112,22 @@ class MoeLayer(nn.Module):
         density_1 = one_hot.mean(dim=-2)
         return (density_1_proxy * density_1).mean() * float(E ** 2)
 
+    @staticmethod
+    def _fusable(selected_experts, gate_softmax, gate_logits=None) -> bool:
+        """The two-launch kernel path (functional.RouterAux) takes what `topk_expert` returns: [B,N,E] fp32 softmax, int32 indices."""
+        return (gate_softmax.is_cuda and gate_softmax.dim() == 3 and gate_softmax.dtype == torch.float32 and gate_softmax.numel() > 0
+                and gate_softmax.shape[-1] <= 1024 and selected_experts.dtype == torch.int32
+                and selected_experts.shape[:-1] == gate_softmax.shape[:-1]
+                and (gate_logits is None or (gate_logits.shape == gate_softmax.shape
+                                             and gate_logits.dtype in (torch.float32, torch.bfloat16))))
+
     def combine_loss(self, selected_experts, gate_softmax, gate_logits, acitve_zloss=True):
+        if self._fusable(selected_experts, gate_softmax, gate_logits if acitve_zloss else None):
+            balance_loss, router_z_loss = RouterAux.apply(gate_logits if acitve_zloss else None, gate_softmax, selected_experts)
+            if acitve_zloss:
+                return (balance_loss * self.args.balance_loss_coef + router_z_loss * self.args.router_z_loss_coef, balance_loss,
+                        router_z_loss)
+            return balance_loss * self.args.balance_loss_coef, balance_loss, router_z_loss
         balance_loss = self.balanceloss(selected_experts=selected_experts, gate_softmax=gate_softmax)
         router_z_loss = gate_softmax.new_zeros(())
         if acitve_zloss:

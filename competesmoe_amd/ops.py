@@ -109,6 +109,38 @@ def router_select_bwd(scores, K, mode, round_sum_bf16, sm, idx, w, dw, dsm):
     return out
 
 
+def router_aux(logits: Optional[torch.Tensor], sm: torch.Tensor, idx: torch.Tensor):
+    """(out2 [2] fp32 = balance, z; dens [B,E] fp32; lse [B*N] fp32 | None) of csmoe_router_aux for sm [B,N,E] fp32, idx [B,N,K]
+    int32 and (optionally) the logits [B,N,E] whose softmax sm is."""
+    _need_cuda(sm, idx, logits)
+    B, N, E = sm.shape
+    K = idx.shape[-1]
+    dev = sm.device
+    out2 = torch.empty(2, dtype=torch.float32, device=dev)
+    dens = torch.empty(B, E, dtype=torch.float32, device=dev)
+    lse = torch.empty(B * N, dtype=torch.float32, device=dev) if logits is not None else None
+    ws = torch.empty(max(1, int(lib.csmoe_router_aux_workspace_floats(B, N, E))), dtype=torch.float32, device=dev)
+    dt = _dt(logits) if logits is not None else L.F32
+    with _timed("router_aux", B * N * E * 4):
+        L.check(lib.csmoe_router_aux(_ptr(logits), sm.data_ptr(), idx.data_ptr(), _ptr(lse), ws.data_ptr(), dens.data_ptr(),
+                                     out2.data_ptr(), B, N, E, K, dt, _stream()), "router_aux")
+    return out2, dens, lse
+
+
+def router_aux_bwd(sm: torch.Tensor, dens: torch.Tensor, lse: Optional[torch.Tensor], g_bal: Optional[torch.Tensor],
+                   g_z: Optional[torch.Tensor], logits_dtype):
+    """(dsoftmax fp32 | None, dlogits logits_dtype | None) of csmoe_router_aux_bwd; g_bal / g_z are 1-element fp32 device tensors."""
+    B, N, E = sm.shape
+    dsm = torch.empty_like(sm) if g_bal is not None else None
+    dlogits = torch.empty(B, N, E, dtype=logits_dtype, device=sm.device) if (g_z is not None and lse is not None) else None
+    if dsm is None and dlogits is None:
+        return None, None
+    dt = L.BF16 if logits_dtype == torch.bfloat16 else L.F32
+    L.check(lib.csmoe_router_aux_bwd(sm.data_ptr(), dens.data_ptr(), _ptr(lse), _ptr(g_bal), _ptr(g_z), _ptr(dsm), _ptr(dlogits),
+                                     B, N, E, dt, _stream()), "router_aux_bwd")
+    return dsm, dlogits
+
+
 # ------------------------------------------------------------------------------------------------ binning
 class Bins:
     """Binned row space of one routing decision."""

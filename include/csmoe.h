@@ -161,6 +161,17 @@ int csmoe_grouped_colsum(const void* G, int64_t ldg, const int32_t* offsets, int
 
 int csmoe_dense_colsum(const void* G, int64_t ldg, int M, int N, void* out, int dtype, int out_dtype, csmoe_stream_t stream);
 
+/* Router auxiliary losses of the LLaVA stack (moe.py:71-110): out2[0] = balance loss (fp32), out2[1] = z-loss (each step rounded
+ * to x.dtype like the reference's tensor ops; 0 when logits == null).  softmax [B,N,E] fp32 = softmax of logits, idx [B,N,K]
+ * (column 0 = top-1).  Keeps dens [B,E] (fraction of tokens whose top-1 is e) and lse [B*N] for the backward; workspace =
+ * csmoe_router_aux_workspace_floats(B, N, E) floats.  Backward: dsoftmax (fp32, from d balance) and dlogits (x.dtype, from d z)
+ * given the device scalars g_balance / g_z; either output may be null. */
+int64_t csmoe_router_aux_workspace_floats(int B, int N, int E);
+int csmoe_router_aux(const void* logits, const float* softmax, const int32_t* idx, float* lse, float* workspace, float* dens,
+                     float* out2, int B, int N, int E, int K, int dtype, csmoe_stream_t stream);
+int csmoe_router_aux_bwd(const float* softmax, const float* dens, const float* lse, const float* g_balance, const float* g_z,
+                         float* dsoftmax, void* dlogits, int B, int N, int E, int dtype, csmoe_stream_t stream);
+
 /* Gate backward for few experts (E <= 4, D a multiple of 8 (bf16) / 4 (fp32), 16-byte aligned rows; csmoe_gate_bwd_small_ok):
  * dx[T,D] = dlogits[T,E] @ w_gate[E,D] and the partial sums of dWg = dlogits^T @ x over csmoe_gate_bwd_dw_ranges(T, D, dtype)
  * row ranges (partial [nranges][E][D] fp32; their sum over the ranges -- csmoe_dense_colsum over [nranges, E*D] -- is dWg).

@@ -48,6 +48,22 @@ def _worker(rank, world, port, T, D, E, K, q):
         e_sorted = idx.flatten()[perm].long()
         exp = xs * (e_sorted + 1).unsqueeze(1).float()
         ok = torch.equal(y, exp)
+        # chunked exchange (groups of local experts, per-peer row views): same rows back, group by group
+        plan2 = ep.make_plan(counts.int(), None, per_expert=True)
+        assert plan2.send_splits == plan.send_splits and plan2.recv_splits == plan.recv_splits and plan2.R == plan.R
+        for chunks in (1, 2, 3, El):
+            cps = ep.chunk_plan(plan2, chunks)
+            assert [c.e0 for c in cps][0] == 0 and cps[-1].e1 == El and sum(c.R for c in cps) == plan.R
+            y2 = torch.full_like(xs, float("nan"))
+            for cp in cps:
+                r = torch.empty(cp.R, D)
+                ep.exchange_views(ep._packed_views(r, cp.recv_n), ep._views(xs, cp.send_lo, cp.send_n)).wait()
+                ids_c = ep.local_expert_ids(plan2, cp.e0, cp.e1)
+                assert ids_c.numel() == cp.R and (cp.R == 0 or int(ids_c.max()) < cp.e1 - cp.e0)
+                gid_c = ids_c.long() + cp.e0 + rank * El
+                ret = r * (gid_c + 1).unsqueeze(1).float()
+                ep.exchange_views(ep._views(y2, cp.send_lo, cp.send_n), ep._packed_views(ret, cp.recv_n)).wait()
+            ok = ok and torch.equal(y2, exp)
         # all ranks' counts line up: recv_counts[s] == rank s's send counts for my experts
         allc = [torch.zeros(E, dtype=torch.int32) for _ in range(world)]
         dist.all_gather(allc, counts.int())

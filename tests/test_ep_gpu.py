@@ -31,7 +31,7 @@ def _experts(E, D, F, seed, dt, dev):
     return ex.to(dev).to(dt)
 
 
-def _run(rank, world, port, backend, dt_name, q):
+def _run(rank, world, port, backend, dt_name, q, chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dev = torch.device("cuda", 0)
@@ -54,7 +54,7 @@ def _run(rank, world, port, backend, dt_name, q):
         full = get_moe("smoe")(D, D, E, K, _experts(E, D, F, 7, dt, dev), args).to(dev).to(dt).train()
         El = E // world
         local = nn.ModuleList([_experts(E, D, F, 7, dt, dev)[rank * El + i] for i in range(El)])
-        epl = ep.EPSMoeLayer(D, D, E, K, local, args).to(dev).to(dt).train()
+        epl = ep.EPSMoeLayer(D, D, E, K, local, args, chunks=chunks).to(dev).to(dt).train()
         g = torch.Generator().manual_seed(50 + rank)
         x = torch.randn(B, N, D, generator=g).to(dt).to(dev)
         dy = torch.randn(B, N, D, generator=g).to(dt).to(dev)
@@ -95,11 +95,11 @@ def _run(rank, world, port, backend, dt_name, q):
         dist.destroy_process_group()
 
 
-def _launch(world, backend, dt_name):
+def _launch(world, backend, dt_name, chunks=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, backend, dt_name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, backend, dt_name, q, chunks)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -118,6 +118,18 @@ def test_ep_world2_one_gpu_equals_single_gpu(dt_name):
     assert _launch(2, "gloo", dt_name) == {0: True, 1: True}
 
 
+@pytest.mark.parametrize("chunks", [2, 3, 8])
+def test_ep_chunked_world1_rccl_equals_single_gpu(chunks):
+    """The overlapped exchange (async list all-to-all on the RCCL process group's stream, groups of local experts): bit-identical
+    to the single-GPU layer.  chunks = 3 gives uneven groups, chunks = 8 one expert per group."""
+    assert _launch(1, "nccl", "bf16", chunks) == {0: True}
+
+
+@pytest.mark.parametrize("dt_name,chunks", [("fp32", 2), ("bf16", 4)])
+def test_ep_chunked_world2_one_gpu_equals_single_gpu(dt_name, chunks):
+    assert _launch(2, "gloo", dt_name, chunks) == {0: True, 1: True}
+
+
 def test_bench_script_runs_small_config_and_ep_path():
     """bench.py end to end on a small layer: the single-GPU path and (with --force-ep, world size 1 over RCCL) the exact code
     path the driver launches for N > 1.  One JSON line with the contract's keys."""
@@ -127,7 +139,7 @@ def test_bench_script_runs_small_config_and_ep_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--tokens", "2048", "--seq", "512", "--d-model", "256", "--d-ff", "512",
             "--experts", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    for extra in ([], ["--force-ep"]):
+    for extra in ([], ["--force-ep"], ["--force-ep", "--ep-chunks", "2"]):
         env = dict(os.environ, MASTER_PORT=str(_free_port()))
         r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -138,4 +150,5 @@ def test_bench_script_runs_small_config_and_ep_path():
             assert k in d, k
         assert d["value"] > 0 and d["n_gpus"] == 1 and d["config"]["workload"]
         if extra:
-            assert "ep_all_to_all" in d["kernels"]
+            assert ("ep_wait_exposed" if "--ep-chunks" in extra else "ep_all_to_all") in d["kernels"]
+            assert d["config"]["ep_chunks"] == (2 if "--ep-chunks" in extra else 1)

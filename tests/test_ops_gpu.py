@@ -461,3 +461,38 @@ def test_gate_small_kernels(dt, T, D, E):
     dw = ops.gate_bwd_dw(dl, x, torch.float32)
     assert rel_l2_(dw, dl.float().t() @ x.float()) <= (1e-5 if dt == torch.float32 else 1e-4)
     assert not ops.gate_bwd_small_ok(D, 64, dt)
+
+
+# ------------------------------------------------------------------------------------------------ router aux losses
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,E,K", [(1, 1, 2, 1), (2, 96, 8, 2), (3, 700, 64, 2), (16, 2048, 64, 2), (2, 513, 300, 4), (5, 33, 4, 2)])
+def test_router_aux_matches_torch_autograd(dt, B, N, E, K):
+    """balance (moe.py:90-110) and z-loss (moe.py:71-88) kernels against the torch formulation of the oracle, values and gradients."""
+    from competesmoe_amd.functional import RouterAux, RouterSelect
+    torch.manual_seed(B * 1000 + N + E)
+    logits = (torch.randn(B, N, E, device=DEV) * 2).to(dt)
+    with torch.no_grad():
+        sm, idx, _ = RouterSelect.apply(logits.reshape(-1, E), K, L.SEL_SOFTMAX, dt == torch.bfloat16)
+    idx = idx.view(B, N, K)
+    # torch reference on the same softmax values
+    lr = logits.clone().requires_grad_(True)
+    sr = sm.view(B, N, E).clone().requires_grad_(True)
+    dens = torch.nn.functional.one_hot(idx[..., 0].long(), E).float().mean(dim=-2)
+    bal_ref = (sr.mean(dim=-2) * dens).mean() * float(E ** 2)
+    z_ref = torch.square(torch.logsumexp(lr, dim=-1)).mean()
+    (bal_ref * 0.7 + z_ref.float() * 1.3).backward()
+    lk = logits.clone().requires_grad_(True)
+    sk = sm.view(B, N, E).clone().requires_grad_(True)
+    bal, z = RouterAux.apply(lk, sk, idx)
+    assert bal.dtype == torch.float32 and z.dtype == dt and bal.dim() == 0 and z.dim() == 0
+    (bal * 0.7 + z.float() * 1.3).backward()
+    assert abs(float(bal) - float(bal_ref)) <= 1e-5 * abs(float(bal_ref))
+    ztol = 1e-5 if dt == torch.float32 else 2.0 ** -7        # bf16: the reference rounds lse, its square and the mean to bf16
+    assert abs(float(z) - float(z_ref)) <= ztol * abs(float(z_ref)), (float(z), float(z_ref))
+    assert (sk.grad - sr.grad).abs().max() <= 1e-6 * sr.grad.abs().max() + 1e-12
+    gtol = 1e-5 if dt == torch.float32 else 2.0 ** -6
+    gk, gr = lk.grad.float(), lr.grad.float()
+    assert float((gk - gr).norm() / gr.norm()) <= gtol
+    # balance alone
+    b2, z2 = RouterAux.apply(None, sm.view(B, N, E), idx)
+    assert float(b2) == float(bal) and float(z2) == 0.0
