@@ -162,7 +162,7 @@ def main():
     Bsz = max(1, T // a.seq)
     Nseq = T // Bsz
     if a.stack == "pretrain":
-        assert world == 1 and not (a.force_ep or a.block or a.block_unfused or a.competition), "--stack pretrain: single-GPU smoe step only"
+        assert world == 1 and not (a.force_ep or a.competition), "--stack pretrain: single-GPU smoe step (optionally --block) only"
         layer = make_pretrain_layer(a, dev)
     elif world > 1 or a.force_ep:
         assert a.experts % world == 0, "experts must divide over ranks"
@@ -170,7 +170,12 @@ def main():
     else:
         layer = make_layer(a, dev, dt)
     blk = ln = None
-    if a.block or a.block_unfused:
+    if (a.block or a.block_unfused) and a.stack == "pretrain":
+        ln = nn.LayerNorm(D).to(dev)                       # fp32 parameters, fp32 residual stream (relative_moe_transformer.py:128-129)
+        if a.block:
+            from competesmoe_amd.pretrain import MoEBlock as PretrainBlock
+            blk = PretrainBlock(ln, layer, 0.0).train()
+    elif a.block or a.block_unfused:
         ln = nn.LayerNorm(D, eps=1e-6).to(dev).to(dt)
         if a.block:
             from competesmoe_amd.moe import MoEBlock
@@ -189,8 +194,16 @@ def main():
             p.grad = None
         x.grad = None
         if a.stack == "pretrain":
+            if ln is not None:
+                ln.weight.grad = ln.bias.grad = None
+            x32.grad = None
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                out = layer(x32, id_layer=0)
+                if blk is not None:
+                    out = blk(x32, id_layer=0)
+                elif ln is not None:
+                    out = x32 + layer(ln(x32), id_layer=0)
+                else:
+                    out = layer(x32, id_layer=0)
                 reg = sum(layer.get_reg_loss().values())
             torch.autograd.backward([out, reg.float()], [dy32.to(out.dtype), one])
             return

@@ -59,6 +59,10 @@ SIGNATURES = {
     "csmoe_layernorm_gate": (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
     "csmoe_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "csmoe_layernorm_bwd_blocks": (_i, [_i]),
+    "csmoe_layernorm_gate_mixed": (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
+    "csmoe_layernorm_bwd_mixed": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "csmoe_combine_mixed": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "csmoe_combine_bwd_mixed": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 
 

@@ -146,6 +146,45 @@ __device__ __forceinline__ typename Chunk<T>::V load_grad(const T* a, const T* b
   return va;
 }
 
+// four waves -> one partial row per workgroup, 1024 columns at a time (32 KiB of LDS: a [4][2][D] buffer would be 128 KiB at
+// D = 4096 and leave ONE workgroup = four waves per CU for a kernel that lives on bytes in flight)
+template <int CPL, int N>
+__device__ __forceinline__ void ln_partial_rows(float (&dg)[CPL][N], float (&db)[CPL][N], float* red /* [4 waves][2][1024] */,
+                                                float* __restrict__ partial, int D, int lane, int wave) {
+  const int nch = D / N;
+  constexpr int GP = 1024 / (64 * N);              // chunk groups (64 chunks = 64 * N columns each) per pass
+#pragma unroll
+  for (int c0 = 0; c0 < CPL; c0 += GP) {
+    if (c0 * 64 * N < D) {                          // uniform
+#pragma unroll
+      for (int cc = 0; cc < GP; ++cc) {
+        const int c = c0 + cc;
+        if (c < CPL) {
+          const int ci = c * 64 + lane;
+          if (ci < nch) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+              red[(wave * 2 + 0) * 1024 + (cc * 64 + lane) * N + e] = dg[c][e];
+              red[(wave * 2 + 1) * 1024 + (cc * 64 + lane) * N + e] = db[c][e];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int col0 = c0 * 64 * N;
+      for (int o = threadIdx.x; o < 2 * 1024; o += 256) {
+        const int which = o >> 10, cl = o & 1023;
+        if (col0 + cl < D) {
+          const float sum = (red[(0 * 2 + which) * 1024 + cl] + red[(1 * 2 + which) * 1024 + cl]) +
+                            (red[(2 * 2 + which) * 1024 + cl] + red[(3 * 2 + which) * 1024 + cl]);
+          partial[(int64_t)blockIdx.x * 2 * D + which * D + col0 + cl] = sum;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------------------------- backward
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ add],  g = dxn * gamma,  xhat = (x - mean) * rstd
 // Persistent grid; wave w of workgroup b walks rows (it * gridDim + b) * 4 + w.  A lane always owns the same columns, so the
@@ -217,40 +256,175 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ dxn, 
       }
     }
   }
-  // four waves -> one partial row per workgroup, 1024 columns at a time (32 KiB of LDS: a [4][2][D] buffer would be 128 KiB at
-  // D = 4096 and leave ONE workgroup = four waves per CU for a kernel that lives on bytes in flight)
-  float* red = (float*)lds;                        // [4 waves][2][1024]
-  constexpr int GP = 1024 / (64 * N);              // chunk groups (64 chunks = 64 * N columns each) per pass
+  ln_partial_rows<CPL, N>(dg, db, (float*)lds, partial, D, lane, wave);
+}
+
+// ------------------------------------------------------------------------------------------------- mixed precision
+// The pretrain stack runs under bf16 autocast with an fp32 residual stream (relative_moe_transformer.py:153-161): LayerNorm is an
+// fp32 op there (fp32 x, fp32 affine parameters), its output is cast to bf16 by the gate's F.linear and by cvmm, the MoE output
+// (bf16) is added to the fp32 residual in fp32.  These kernels read / write the fp32 stream directly: xn leaves as bf16 (one
+// rounding of the fp32 result, what the two casts produce), the backward takes the two bf16 gradient streams of xn (autograd
+// sums their fp32 casts: no rounding of the sum), fp32 x and the fp32 residual-path gradient, and writes fp32 dx.
+// A chunk is 8 columns: 32 bytes of x (two 16-byte loads), 16 bytes of xn / dxn.
+struct X8 { f32x4 a, b; };
+__device__ __forceinline__ X8 ld_x8(const float* p) { return X8{*(const f32x4*)p, *(const f32x4*)(p + 4)}; }
+__device__ __forceinline__ void unpack_x8(const X8& v, float (&f)[8]) {
 #pragma unroll
-  for (int c0 = 0; c0 < CPL; c0 += GP) {
-    if (c0 * 64 * N < D) {                          // uniform
+  for (int j = 0; j < 4; ++j) { f[j] = v.a[j]; f[4 + j] = v.b[j]; }
+}
+
+__global__ void __launch_bounds__(256) ln_fwd_mixed_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, bf16* __restrict__ xn,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out, int Tn, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int CPL_MAX = CPL_MAX_B / 8;          // 8 chunks per lane at D = 4096
+  const int nch = D / 8;
+  const int row0 = blockIdx.x * LN_ROWS;
+  for (int jj = 0; jj < 4; jj += 2) {
+    X8 v[2][CPL_MAX];
+    float mean[2], rstd[2];
+    bool live[2];
 #pragma unroll
-      for (int cc = 0; cc < GP; ++cc) {
-        const int c = c0 + cc;
-        if (c < CPL) {
+    for (int h = 0; h < 2; ++h) {
+      const int R = row0 + wave * 4 + jj + h;
+      live[h] = R < Tn;
+      if (live[h]) {
+#pragma unroll
+        for (int c = 0; c < CPL_MAX; ++c) {
           const int ci = c * 64 + lane;
-          if (ci < nch) {
+          if (ci < nch) v[h][c] = ld_x8(x + (int64_t)R * D + (int64_t)ci * 8);
+        }
+      }
+    }
 #pragma unroll
-            for (int e = 0; e < N; ++e) {
-              red[(wave * 2 + 0) * 1024 + (cc * 64 + lane) * N + e] = dg[c][e];
-              red[(wave * 2 + 1) * 1024 + (cc * 64 + lane) * N + e] = db[c][e];
-            }
+    for (int h = 0; h < 2; ++h) {
+      float s = 0.f;
+      if (live[h]) {
+#pragma unroll
+        for (int c = 0; c < CPL_MAX; ++c) {
+          if (c * 64 + lane < nch) {
+            float f[8];
+            unpack_x8(v[h][c], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[e];
           }
         }
       }
-      __syncthreads();
-      const int col0 = c0 * 64 * N;
-      for (int o = threadIdx.x; o < 2 * 1024; o += 256) {
-        const int which = o >> 10, cl = o & 1023;
-        if (col0 + cl < D) {
-          const float sum = (red[(0 * 2 + which) * 1024 + cl] + red[(1 * 2 + which) * 1024 + cl]) +
-                            (red[(2 * 2 + which) * 1024 + cl] + red[(3 * 2 + which) * 1024 + cl]);
-          partial[(int64_t)blockIdx.x * 2 * D + which * D + col0 + cl] = sum;
+      mean[h] = wave_sum(s) / (float)D;
+      float q = 0.f;
+      if (live[h]) {
+#pragma unroll
+        for (int c = 0; c < CPL_MAX; ++c) {
+          if (c * 64 + lane < nch) {
+            float f[8];
+            unpack_x8(v[h][c], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[e] - mean[h]; q += d * d; }
+          }
         }
       }
-      __syncthreads();
+      rstd[h] = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int R = row0 + wave * 4 + jj + h;
+      if (!live[h]) continue;
+      if (lane == 0) { mean_out[R] = mean[h]; rstd_out[R] = rstd[h]; }
+#pragma unroll
+      for (int c = 0; c < CPL_MAX; ++c) {
+        const int ci = c * 64 + lane;
+        if (ci < nch) {
+          float f[8], gm[8], bt[8];
+          unpack_x8(v[h][c], f);
+          if (gamma) unpack_x8(ld_x8(gamma + (int64_t)ci * 8), gm);
+          if (beta) unpack_x8(ld_x8(beta + (int64_t)ci * 8), bt);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean[h]) * rstd[h] * (gamma ? gm[e] : 1.f) + (beta ? bt[e] : 0.f);
+          *(bf16x8*)(xn + (int64_t)R * D + (int64_t)ci * 8) = Chunk<bf16>::pack(f);
+        }
+      }
     }
   }
+}
+
+__device__ __forceinline__ void load_grad_mixed(const bf16* a, const bf16* b, int64_t off, float (&g)[8]) {
+  Chunk<bf16>::unpack(*(const bf16x8*)(a + off), g);
+  if (b) {
+    float fb[8];
+    Chunk<bf16>::unpack(*(const bf16x8*)(b + off), fb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] += fb[e];          // fp32 sum of the two casts, not rounded
+  }
+}
+
+template <int CPL, bool KEEP>
+__global__ void __launch_bounds__(256) ln_bwd_mixed_kernel(const bf16* __restrict__ dxn, const bf16* __restrict__ dxn2,
+                                                           const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                           const float* __restrict__ add, float* __restrict__ dx,
+                                                           float* __restrict__ partial, int Tn, int D) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int N = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D / N;
+  float dg[CPL][N], db[CPL][N];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+#pragma unroll
+    for (int e = 0; e < N; ++e) { dg[c][e] = 0.f; db[c][e] = 0.f; }
+  const float invD = 1.f / (float)D;
+  for (int R = blockIdx.x * 4 + wave; R < Tn; R += gridDim.x * 4) {
+    const float mean = mean_in[R], rstd = rstd_in[R];
+    X8 vx[KEEP ? CPL : 1];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int ci = c * 64 + lane;
+      if (ci < nch) {
+        const int64_t off = (int64_t)R * D + (int64_t)ci * N;
+        const X8 ax = ld_x8(x + off);
+        if (KEEP) vx[c] = ax;
+        float fx[N], fg[N], gm[N];
+        unpack_x8(ax, fx);
+        load_grad_mixed(dxn, dxn2, off, fg);
+        if (gamma) unpack_x8(ld_x8(gamma + (int64_t)ci * N), gm);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float xh = (fx[e] - mean) * rstd;
+          const float g = fg[e] * (gamma ? gm[e] : 1.f);
+          s1 += g;
+          s2 += g * xh;
+          dg[c][e] += fg[e] * xh;
+          db[c][e] += fg[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int ci = c * 64 + lane;
+      if (ci < nch) {
+        const int64_t off = (int64_t)R * D + (int64_t)ci * N;
+        const X8 ax = KEEP ? vx[c] : ld_x8(x + off);
+        float fx[N], fg[N], gm[N], fa[N];
+        unpack_x8(ax, fx);
+        load_grad_mixed(dxn, dxn2, off, fg);              // bf16 gradient rows re-read from L2 (half the bytes of x)
+        if (gamma) unpack_x8(ld_x8(gamma + (int64_t)ci * N), gm);
+        if (add) unpack_x8(ld_x8(add + off), fa);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float xh = (fx[e] - mean) * rstd;
+          float r = rstd * (fg[e] * (gamma ? gm[e] : 1.f) - s1 - xh * s2);
+          if (add) r += fa[e];
+          fx[e] = r;
+        }
+        *(f32x4*)(dx + off) = f32x4{fx[0], fx[1], fx[2], fx[3]};
+        *(f32x4*)(dx + off + 4) = f32x4{fx[4], fx[5], fx[6], fx[7]};
+      }
+    }
+  }
+  ln_partial_rows<CPL, N>(dg, db, (float*)lds, partial, D, lane, wave);
 }
 
 template <typename K>
@@ -311,5 +485,36 @@ int k_layernorm_bwd(const void* dxn, const void* dxn2, const void* x, const void
   }
   if (rc) return rc;
   CSMOE_CHECK_LAUNCH("layernorm_bwd");
+  return CSMOE_OK;
+}
+
+int k_layernorm_fwd_mixed(const float* x, const float* gamma, const float* beta, float eps, void* xn, float* mean, float* rstd, int T,
+                          int D, hipStream_t st) {
+  dim3 grid((T + LN_ROWS - 1) / LN_ROWS), block(256);
+  hipLaunchKernelGGL(ln_fwd_mixed_kernel, grid, block, 0, st, x, gamma, beta, eps, (bf16*)xn, mean, rstd, T, D);
+  CSMOE_CHECK_LAUNCH("layernorm_gate_mixed");
+  return CSMOE_OK;
+}
+
+template <int CPL, bool KEEP>
+static int launch_ln_bwd_mixed(const void* dxn, const void* dxn2, const float* x, const float* gamma, const float* mean, const float* rstd,
+                               const float* add, float* dx, float* partial, int Tn, int D, hipStream_t st) {
+  dim3 grid(k_layernorm_bwd_blocks(Tn)), block(256);
+  const int bytes = 4 * 2 * 1024 * 4;
+  int rc;
+  if ((rc = raise_lds(ln_bwd_mixed_kernel<CPL, KEEP>, bytes, "layernorm_bwd_mixed"))) return rc;
+  hipLaunchKernelGGL((ln_bwd_mixed_kernel<CPL, KEEP>), grid, block, bytes, st, (const bf16*)dxn, (const bf16*)dxn2, x, gamma, mean, rstd, add, dx,
+                     partial, Tn, D);
+  return CSMOE_OK;
+}
+
+int k_layernorm_bwd_mixed(const void* dxn, const void* dxn2, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* add, float* dx, float* partial, int T, int D, hipStream_t st) {
+  const int cpl = (D / 8 + 63) / 64;             // <= 8 for D <= 4096
+  int rc = cpl <= 2 ? launch_ln_bwd_mixed<2, true>(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, st)
+         : cpl <= 4 ? launch_ln_bwd_mixed<4, true>(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, st)
+                    : launch_ln_bwd_mixed<8, false>(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, st);
+  if (rc) return rc;
+  CSMOE_CHECK_LAUNCH("layernorm_bwd_mixed");
   return CSMOE_OK;
 }

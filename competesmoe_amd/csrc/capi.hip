@@ -41,6 +41,14 @@ int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, 
 int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
 int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st);
 int k_expert_order(const int32_t* offsets, int E, int32_t* order, hipStream_t st);
+int k_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const float* add, float* out, int T, int K,
+                    int D, int mode, hipStream_t st);
+int k_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of, const float* w, void* dy, float* dw, int T, int K,
+                        int D, hipStream_t st);
+int k_layernorm_fwd_mixed(const float* x, const float* gamma, const float* beta, float eps, void* xn, float* mean, float* rstd, int T,
+                          int D, hipStream_t st);
+int k_layernorm_bwd_mixed(const void* dxn, const void* dxn2, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* add, float* dx, float* partial, int T, int D, hipStream_t st);
 int64_t k_router_aux_workspace_floats(int B, int N, int E);
 int k_router_aux_fwd(const void* logits, const float* sm, const int32_t* idx, float* lse, float* partial, float* dens, float* out2,
                      int B, int N, int E, int K, int dtype, hipStream_t st);
@@ -387,4 +395,48 @@ int csmoe_layernorm_bwd(const void* dxn, const void* dxn2, const void* x, const 
   CSMOE_CHECK_ARG(((((uintptr_t)x | (uintptr_t)dxn | (uintptr_t)dxn2 | (uintptr_t)gamma | (uintptr_t)add | (uintptr_t)dx) & 15) == 0),
                   "layernorm_bwd: operands must be 16-byte aligned");
   return k_layernorm_bwd(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, dtype, (hipStream_t)stream);
+}
+
+// ---- fp32 residual stream around bf16 activations (pretrain stack under autocast): mixed-precision forms of the block kernels
+int csmoe_layernorm_gate_mixed(const float* x, const float* gamma, const float* beta, float eps, void* xn, float* mean, float* rstd,
+                               int T, int D, const void* w_gate, void* logits, int E, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(T >= 0 && D > 0 && D <= k_layernorm_max_d(CSMOE_BF16) && D % 8 == 0,
+                  "layernorm_gate_mixed: D=%d unsupported (multiple of 8, at most %d)", D, k_layernorm_max_d(CSMOE_BF16));
+  CSMOE_CHECK_ARG(eps >= 0.f, "layernorm_gate_mixed: eps < 0");
+  CSMOE_CHECK_ARG((w_gate == nullptr) == (logits == nullptr) && (w_gate == nullptr || E > 0), "layernorm_gate_mixed: w_gate / logits / E");
+  if (T == 0) return CSMOE_OK;
+  CSMOE_CHECK_ARG(x && xn && mean && rstd, "layernorm_gate_mixed: null pointer");
+  CSMOE_CHECK_ARG(((((uintptr_t)x | (uintptr_t)xn | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_gate) & 15) == 0),
+                  "layernorm_gate_mixed: operands must be 16-byte aligned");
+  int rc = k_layernorm_fwd_mixed(x, gamma, beta, eps, xn, mean, rstd, T, D, (hipStream_t)stream);
+  if (rc || !w_gate) return rc;
+  return csmoe_gate_logits(xn, w_gate, logits, T, D, E, CSMOE_BF16, stream);
+}
+
+int csmoe_layernorm_bwd_mixed(const void* dxn, const void* dxn2, const float* x, const float* gamma, const float* mean,
+                              const float* rstd, const float* add, float* dx, float* partial, int T, int D, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(T >= 0 && D > 0 && D <= k_layernorm_max_d(CSMOE_BF16) && D % 8 == 0, "layernorm_bwd_mixed: D=%d unsupported", D);
+  CSMOE_CHECK_ARG(partial, "layernorm_bwd_mixed: null pointer");
+  CSMOE_CHECK_ARG(T == 0 || (dxn && x && mean && rstd && dx), "layernorm_bwd_mixed: null pointer");
+  CSMOE_CHECK_ARG(((((uintptr_t)x | (uintptr_t)dxn | (uintptr_t)dxn2 | (uintptr_t)gamma | (uintptr_t)add | (uintptr_t)dx) & 15) == 0),
+                  "layernorm_bwd_mixed: operands must be 16-byte aligned");
+  return k_layernorm_bwd_mixed(dxn, dxn2, x, gamma, mean, rstd, add, dx, partial, T, D, (hipStream_t)stream);
+}
+
+int csmoe_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const float* residual, float* out,
+                        int T, int K, int D, int mode, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(K > 0 && K <= 64 && T >= 0 && D > 0 && D % 8 == 0, "combine_mixed: bad arguments (K <= 64, D a multiple of 8)");
+  CSMOE_CHECK_ARG(mode >= 0 && mode <= 2, "combine_mixed: bad mode %d", mode);
+  CSMOE_CHECK_ARG(T == 0 || (y && slot_of && w && out), "combine_mixed: null pointer");
+  CSMOE_CHECK_ARG(T == 0 || mode == CSMOE_COMBINE_DOT || idx, "combine_mixed: idx required for the sequential rounding rule");
+  CSMOE_CHECK_ARG((((uintptr_t)y | (uintptr_t)residual | (uintptr_t)out) & 15) == 0, "combine_mixed: operands must be 16-byte aligned");
+  return k_combine_mixed(y, slot_of, idx, w, residual, out, T, K, D, mode, (hipStream_t)stream);
+}
+
+int csmoe_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of, const float* w, void* dy, float* dw, int T, int K,
+                            int D, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(K > 0 && T >= 0 && D > 0 && D % 8 == 0, "combine_bwd_mixed: bad arguments (D a multiple of 8)");
+  CSMOE_CHECK_ARG(T == 0 || (dout && slot_of && dy), "combine_bwd_mixed: null pointer");
+  CSMOE_CHECK_ARG((((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0, "combine_bwd_mixed: operands must be 16-byte aligned");
+  return k_combine_bwd_mixed(dout, y, slot_of, w, dy, dw, T, K, D, (hipStream_t)stream);
 }

@@ -1,6 +1,7 @@
 // HBM-bound kernels of the sparse-MoE hot path for gfx950: router selection, token binning, dispatch / combine,
 // bias-gradient column sums and the competition affinity reduction.  One wave (64 lanes) per token row, 16-byte
 // vector accesses, wavefront shuffles for the row reductions / arg-max.
+#include <type_traits>
 #include "common.h"
 #include <algorithm>
 
@@ -303,10 +304,14 @@ __global__ void __launch_bounds__(256) dispatch_tokens_kernel(const char* x, con
 // Combine  (moe.py:204 / cvmm.py:481-483) and the dispatch backward gather-sum (cvmm.py:544-545)
 // =====================================================================================================================
 
-template <typename T, int VEC>
+// TO = type of the residual `add` and of `out`: T, or float with T = bf16 (the pretrain stack's fp32 residual stream under
+// bf16 autocast: the combine result is rounded to bf16 like the reference's cvmm output, then added to the fp32 residual in fp32)
+template <typename T, int VEC, typename TO = T>
 __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t* slot_of, const int32_t* idx, const float* w,
-                                                      const T* obias, const T* add, T* out, int Tn, int K, int D, int mode) {
+                                                      const T* obias, const TO* add, TO* out, int Tn, int K, int D, int mode) {
 #pragma clang fp contract(off)   // the sequential rule is "multiply, round, add, round": no FMA contraction
+  constexpr bool O32 = !std::is_same<T, TO>::value;
+  static_assert(!O32 || (std::is_same<TO, float>::value && VEC == 8), "mixed combine: bf16 rows, fp32 residual / output, 8-column chunks");
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
@@ -340,8 +345,12 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
 #pragma unroll
       for (int v = 0; v < VEC; ++v) addv[v] = 0.f;
       if (add && live) {
-        const T* arow = add + (int64_t)t * D + d0;
-        if constexpr (VEC == 8) {
+        const TO* arow = add + (int64_t)t * D + d0;
+        if constexpr (O32) {
+          const f32x4 ra = *(const f32x4*)arow, rb = *(const f32x4*)(arow + 4);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) { addv[v] = ra[v]; addv[4 + v] = rb[v]; }
+        } else if constexpr (VEC == 8) {
           bf16x8 r8 = *(const bf16x8*)arow;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) addv[v] = (float)r8[v];
@@ -350,7 +359,7 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
 #pragma unroll
           for (int v = 0; v < VEC; ++v) addv[v] = r4[v];
         } else {
-          addv[0] = DT<T>::ld(arow);
+          addv[0] = DT<TO>::ld(arow);
         }
       }
       for (int kk = 0; kk < K; ++kk) {
@@ -393,11 +402,14 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
         float r = acc[v];
         if (mode == CSMOE_COMBINE_DOT) r = DT<T>::rnd(r);
         if (obias) r = DT<T>::rnd(r + DT<T>::ld(obias + d0 + v));
-        if (add) r = DT<T>::rnd(r + addv[v]);
+        if (add) r = DT<TO>::rnd(r + addv[v]);
         acc[v] = r;
       }
-      T* o = out + (int64_t)t * D + d0;
-      if constexpr (VEC == 8) {
+      TO* o = out + (int64_t)t * D + d0;
+      if constexpr (O32) {
+        *(f32x4*)o = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *(f32x4*)(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+      } else if constexpr (VEC == 8) {
         bf16x8 o8;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o8[v] = (bf16)acc[v];
@@ -405,7 +417,7 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
       } else if constexpr (VEC == 4) {
         *(f32x4*)o = f32x4{acc[0], acc[1], acc[2], acc[3]};
       } else {
-        DT<T>::st(o, acc[0]);
+        DT<TO>::st(o, acc[0]);
       }
     }
   }
@@ -413,9 +425,13 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
 
 // combine backward: one wave per TOKEN, inner loop over its K slots (dout[t] comes from L1/L2 after the first slot, so HBM
 // reads it once): dy[slot] = round(w * dout[t]), dw[t,k] = <dout[t], y[slot]>
-template <typename T, int VEC>
-__global__ void __launch_bounds__(256) combine_bwd_kernel(const T* dout, const T* y, const int32_t* slot_of, const float* w, T* dy,
+// TG = type of the upstream gradient: T, or float with T = bf16 (fp32 residual stream: autograd casts the gradient to bf16 first,
+// i.e. one rounding on load)
+template <typename T, int VEC, typename TG = T>
+__global__ void __launch_bounds__(256) combine_bwd_kernel(const TG* dout, const T* y, const int32_t* slot_of, const float* w, T* dy,
                                                           float* dw, int Tn, int K, int D) {
+  constexpr bool G32 = !std::is_same<T, TG>::value;
+  static_assert(!G32 || (std::is_same<TG, float>::value && VEC == 8), "mixed combine_bwd: fp32 gradient, bf16 rows, 8-column chunks");
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
@@ -426,12 +442,18 @@ __global__ void __launch_bounds__(256) combine_bwd_kernel(const T* dout, const T
       const float wk = w ? w[flat] : 1.f;
       float dot = 0.f;
       for (int d0 = lane * VEC; d0 < D; d0 += 64 * VEC) {
-        const T* g = dout + (int64_t)t * D + d0;
+        const TG* g = dout + (int64_t)t * D + d0;
         float gv[VEC], yv[VEC];
         if constexpr (VEC == 8) {
-          bf16x8 g8 = *(const bf16x8*)g;
+          if constexpr (G32) {
+            const f32x4 ga = *(const f32x4*)g, gb = *(const f32x4*)(g + 4);
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) gv[v] = (float)g8[v];
+            for (int v = 0; v < 4; ++v) { gv[v] = DT<bf16>::rnd(ga[v]); gv[4 + v] = DT<bf16>::rnd(gb[v]); }
+          } else {
+            bf16x8 g8 = *(const bf16x8*)g;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) gv[v] = (float)g8[v];
+          }
           if (y) {
             bf16x8 y8 = *(const bf16x8*)(y + (int64_t)m * D + d0);
 #pragma unroll
@@ -452,7 +474,7 @@ __global__ void __launch_bounds__(256) combine_bwd_kernel(const T* dout, const T
           }
           *(f32x4*)(dy + (int64_t)m * D + d0) = f32x4{gv[0] * wk, gv[1] * wk, gv[2] * wk, gv[3] * wk};
         } else {
-          gv[0] = DT<T>::ld(g);
+          gv[0] = DT<TG>::ld(g);
           if (y) yv[0] = DT<T>::ld(y + (int64_t)m * D + d0);
           DT<T>::st(dy + (int64_t)m * D + d0, gv[0] * wk);
         }
@@ -888,36 +910,44 @@ __global__ void __launch_bounds__(256) router_aux_partial_kernel(const T* logits
   }
 }
 
-// one workgroup: partial rows -> dens[b,e] (kept for the backward), balance, z
+// one workgroup of 1024 threads: partial rows -> dens[b,e] (kept for the backward), balance, z.  One (b, e) output per thread and
+// eight chunk rows in flight per thread: the launch is a chain of dependent loads, not bandwidth.
 template <typename T>
-__global__ void __launch_bounds__(256) router_aux_final_kernel(const float* partial, float* dens, float* out2, int B, int N, int E,
-                                                               int nchunk, int has_z) {
-  __shared__ float acc[256];
+__global__ void __launch_bounds__(1024) router_aux_final_kernel(const float* partial, float* dens, float* out2, int B, int N, int E,
+                                                                int nchunk, int has_z) {
+  __shared__ float acc[1024];
+  const int tid = threadIdx.x;
+  const int64_t rs = 2 * E + 1;
   float bal = 0.f, z = 0.f;
-  for (int o = threadIdx.x; o < B * E; o += 256) {
+  for (int o = tid; o < B * E; o += 1024) {
     const int b = o / E, e = o - b * E;
+    const float* row = partial + (int64_t)b * nchunk * rs + e;
     float p = 0.f, d = 0.f;
-    for (int c = 0; c < nchunk; ++c) {
-      const float* row = partial + (int64_t)(b * nchunk + c) * (2 * E + 1);
-      p += row[e];
-      d += row[E + e];
+    int c = 0;
+    for (; c + 8 <= nchunk; c += 8) {
+      float pv[8], dv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { pv[u] = row[(c + u) * rs]; dv[u] = row[(c + u) * rs + E]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { p += pv[u]; d += dv[u]; }
     }
+    for (; c < nchunk; ++c) { p += row[c * rs]; d += row[c * rs + E]; }
     p /= (float)N;
     d /= (float)N;
     dens[o] = d;
     bal += p * d;
   }
   if (has_z)
-    for (int o = threadIdx.x; o < B * nchunk; o += 256) z += partial[(int64_t)o * (2 * E + 1) + 2 * E];
-  acc[threadIdx.x] = bal;
+    for (int o = tid; o < B * nchunk; o += 1024) z += partial[(int64_t)o * rs + 2 * E];
+  acc[tid] = bal;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) acc[threadIdx.x] += acc[threadIdx.x + st]; __syncthreads(); }
+  for (int st = 512; st > 0; st >>= 1) { if (tid < st) acc[tid] += acc[tid + st]; __syncthreads(); }
   const float bal_tot = acc[0];
   __syncthreads();
-  acc[threadIdx.x] = z;
+  acc[tid] = z;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) acc[threadIdx.x] += acc[threadIdx.x + st]; __syncthreads(); }
-  if (threadIdx.x == 0) {
+  for (int st = 512; st > 0; st >>= 1) { if (tid < st) acc[tid] += acc[tid + st]; __syncthreads(); }
+  if (tid == 0) {
     out2[0] = bal_tot / (float)(B * E) * (float)E * (float)E;
     out2[1] = has_z ? DT<T>::rnd(acc[0] / (float)((int64_t)B * N)) : 0.f;
   }
@@ -1079,6 +1109,25 @@ int k_combine_bwd(const void* dout, const void* y, const int32_t* perm, const fl
   return CSMOE_OK;
 }
 
+// bf16 rows, fp32 residual / output (pretrain stack under autocast); D % 8 == 0 and 16-byte alignment checked by the caller
+int k_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const float* add, float* out, int T, int K,
+                    int D, int mode, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  hipLaunchKernelGGL((combine_kernel<bf16, 8, float>), dim3(stride_grid(T)), dim3(256), 0, st, (const bf16*)y, slot_of, idx, w,
+                     (const bf16*)nullptr, add, out, T, K, D, mode);
+  CSMOE_CHECK_LAUNCH("combine_mixed");
+  return CSMOE_OK;
+}
+
+int k_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of, const float* w, void* dy, float* dw, int T, int K,
+                        int D, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  hipLaunchKernelGGL((combine_bwd_kernel<bf16, 8, float>), dim3(stride_grid(T)), dim3(256), 0, st, dout, (const bf16*)y, slot_of, w,
+                     (bf16*)dy, dw, T, K, D);
+  CSMOE_CHECK_LAUNCH("combine_bwd_mixed");
+  return CSMOE_OK;
+}
+
 int k_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int single_M, int N, void* const* out_ptrs,
              void* single_out, int dtype, int out_dtype, hipStream_t st) {
   if (N == 0 || E == 0) return CSMOE_OK;
@@ -1233,10 +1282,10 @@ int k_router_aux_fwd(const void* logits, const float* sm, const int32_t* idx, fl
   dim3 grid(B * nchunk), block(256);
   if (dtype == CSMOE_BF16) {
     hipLaunchKernelGGL((router_aux_partial_kernel<bf16>), grid, block, 0, st, (const bf16*)logits, sm, idx, lse, partial, N, E, K, nchunk, chunk, lc);
-    hipLaunchKernelGGL((router_aux_final_kernel<bf16>), dim3(1), block, 0, st, partial, dens, out2, B, N, E, nchunk, logits ? 1 : 0);
+    hipLaunchKernelGGL((router_aux_final_kernel<bf16>), dim3(1), dim3(1024), 0, st, partial, dens, out2, B, N, E, nchunk, logits ? 1 : 0);
   } else {
     hipLaunchKernelGGL((router_aux_partial_kernel<float>), grid, block, 0, st, (const float*)logits, sm, idx, lse, partial, N, E, K, nchunk, chunk, lc);
-    hipLaunchKernelGGL((router_aux_final_kernel<float>), dim3(1), block, 0, st, partial, dens, out2, B, N, E, nchunk, logits ? 1 : 0);
+    hipLaunchKernelGGL((router_aux_final_kernel<float>), dim3(1), dim3(1024), 0, st, partial, dens, out2, B, N, E, nchunk, logits ? 1 : 0);
   }
   CSMOE_CHECK_LAUNCH("router_aux_fwd");
   return CSMOE_OK;

@@ -5,6 +5,7 @@ Reference parity notes are on each class (file:line of the reference code whose 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -133,14 +134,21 @@ class LayerNormGate(torch.autograd.Function):
     `layer_norm2` + `self.gate(x)` + `residual + results` of SiglipEncoderMoELayer.forward (siglip_smoe.py:152-155, smoe.py:42)."""
 
     @staticmethod
-    def forward(ctx, x2, gamma, beta, eps: float, w_gate):
+    def forward(ctx, x2, gamma, beta, eps: float, w_gate, act_dtype=None):
+        """`act_dtype` = torch.bfloat16 with fp32 x: the pretrain stack's fp32 residual stream under bf16 autocast
+        (relative_moe_transformer.py:153-161): LayerNorm in fp32, xn / logits leave as bf16 (csmoe_layernorm_gate_mixed)."""
         x2 = x2.contiguous()
+        ctx.mixed = act_dtype == torch.bfloat16 and x2.dtype == torch.float32
+        od = torch.bfloat16 if ctx.mixed else x2.dtype
         wg = w_gate.contiguous()
-        if wg.dtype != x2.dtype:
-            wg = wg.to(x2.dtype)
+        if wg.dtype != od:
+            wg = wg.to(od)
         g = None if gamma is None else gamma.to(x2.dtype).contiguous()
         b = None if beta is None else beta.to(x2.dtype).contiguous()
-        xn, mean, rstd, logits = ops.layernorm_gate(x2, g, b, eps, wg)
+        if ctx.mixed:
+            xn, mean, rstd, logits = ops.layernorm_gate_mixed(x2, g, b, eps, wg)
+        else:
+            xn, mean, rstd, logits = ops.layernorm_gate(x2, g, b, eps, wg)
         ctx.save_for_backward(x2, g, mean, rstd, xn, wg)
         ctx.dtypes = (None if gamma is None else gamma.dtype, None if beta is None else beta.dtype, w_gate.dtype)
         return xn, logits, x2.view_as(x2)
@@ -160,13 +168,14 @@ class LayerNormGate(torch.autograd.Function):
         if a is None:
             a, b2 = dxn_gate, None
         if a is None:                                                      # only the residual carries a gradient
-            return dres, None, None, None, dwg
+            return dres, None, None, None, dwg, None
         want_affine = (gd is not None and ctx.needs_input_grad[1]) or (bd is not None and ctx.needs_input_grad[2])
-        dx, dgamma, dbeta = ops.layernorm_bwd(a.contiguous(), x2, g, mean, rstd, add=None if dres is None else dres.contiguous(),
-                                              want_affine_grads=want_affine, dxn2=None if b2 is None else b2.contiguous())
+        bwd = ops.layernorm_bwd_mixed if ctx.mixed else ops.layernorm_bwd
+        dx, dgamma, dbeta = bwd(a.contiguous(), x2, g, mean, rstd, add=None if dres is None else dres.contiguous(),
+                                want_affine_grads=want_affine, dxn2=None if b2 is None else b2.contiguous())
         dg = dgamma.to(gd) if (want_affine and gd is not None) else None
         db = dbeta.to(bd) if (want_affine and bd is not None) else None
-        return dx, dg, db, None, dwg
+        return dx, dg, db, None, dwg, None
 
 
 # ======================================================================================================== router
@@ -238,7 +247,20 @@ class ExpertTable:
     param_dtype: torch.dtype = torch.float32   # dtype of the gradients handed back
 
 
-def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residual=None):
+_CAST_OVERLAP = os.environ.get("CSMOE_CAST_OVERLAP", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residual=None, before_gemm2=None):
+    """`before_gemm2`: a stream the launch stream must wait for before the second grouped GEMM (operand cast running beside GEMM 1)."""
     T = x2.shape[0]
     bins = ops.bin_tokens(idx, tab.E)
     xs = ops.dispatch_tokens(x2, bins)
@@ -246,6 +268,8 @@ def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residua
     ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
     hpre, hact = ops.grouped_gemm(xs, tab.w1_ptrs, tab.layout, ld1, tab.F, bins.offsets, tab.E, bias_ptrs=tab.b1_ptrs,
                                   epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True)
+    if before_gemm2 is not None:
+        torch.cuda.current_stream().wait_stream(before_gemm2)
     y = ops.grouped_gemm(hact, tab.w2_ptrs, tab.layout, ld2, tab.Dout, bins.offsets, tab.E, bias_ptrs=tab.b2_ptrs,
                          epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
     out = ops.combine(y, bins, idx, w, combine_mode, T, obias=obias, residual=residual)
@@ -258,7 +282,7 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
     T = dout.shape[0]
     dev = dout.device
     E = tab.E
-    dy, dw = ops.combine_bwd(dout.contiguous(), y if need_dw else None, bins, w, want_dw=need_dw)
+    dy, dw = ops.combine_bwd(dout.contiguous(), y if need_dw else None, bins, w, want_dw=need_dw, act_dtype=hpre.dtype)
     ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
     ld1 = tab.D if tab.layout == L.B_NK else tab.F
     # dH = dY @ W2 (+ activation backward in the epilogue)
@@ -363,14 +387,29 @@ class MoEFFNPacked(torch.autograd.Function):
     cast once per call, gradients come back in the master dtype."""
 
     @staticmethod
-    def forward(ctx, x2, w, idx, keys, values, bias, o_bias, act: int, combine_mode: int):
+    def forward(ctx, x2, w, idx, keys, values, bias, o_bias, act: int, combine_mode: int, residual=None):
+        """`residual` [T, Dout] (x2.dtype, or fp32 around bf16 rows): added in the combine epilogue, out = residual + MoE(x2) in
+        the residual's dtype -- the block around the layer (pretrain/block.py); its gradient is the upstream gradient itself."""
         x2 = x2.contiguous()
         op = x2.dtype
         E, D, F = keys.shape
         Dout = values.shape[2]
         dev = x2.device
         k_op = keys.contiguous() if keys.dtype == op else keys.to(op)
-        v_op = values.contiguous() if values.dtype == op else values.to(op)
+        side = None
+        if values.dtype == op:
+            v_op = values.contiguous()
+        elif _CAST_OVERLAP and values.is_contiguous() and values.numel() >= (1 << 24):
+            # fp32 master -> bf16 operand cast of `values` (HBM-bound) on a side stream, under the first grouped GEMM (MFMA-bound),
+            # which only needs `keys`; the buffer is allocated on the launch stream, so its lifetime follows that stream
+            main = torch.cuda.current_stream()
+            side = _side_stream(dev)
+            v_op = torch.empty(values.shape, dtype=op, device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                v_op.copy_(values)
+        else:
+            v_op = values.to(op)
         es = k_op.element_size()
         ar = ops.cached_arange(E, dev)
         b_op = None
@@ -384,7 +423,9 @@ class MoEFFNPacked(torch.autograd.Function):
         tab = ExpertTable(E=E, D=D, F=F, Dout=Dout, layout=L.B_KN, act=act,
                           w1_ptrs=k_op.data_ptr() + ar * (D * F * es), w2_ptrs=v_op.data_ptr() + ar * (F * Dout * es),
                           b1_ptrs=b1, b2_ptrs=None, param_dtype=keys.dtype)
-        out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, ob)
+        out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, ob, residual=None if residual is None else residual.contiguous(),
+                                  before_gemm2=side)
+        ctx.has_residual = residual is not None
         ctx.tab, ctx.saved, ctx.w = tab, saved, w
         ctx.keep = (k_op, v_op, b_op)       # keep the cast copies alive: the pointer tables reference them
         ctx.has = (bias is not None, o_bias is not None)
@@ -406,7 +447,7 @@ class MoEFFNPacked(torch.autograd.Function):
                 gb = gb1 if gb1.dtype == ctx.bias_dtype else gb1.to(ctx.bias_dtype)
         if ctx.has[1] and ctx.needs_input_grad[6]:
             gob = _chunked_dense_colsum(dout.contiguous(), ctx.ob_dtype)
-        return dx2, dw, None, gk, gv, gb, gob, None, None
+        return dx2, dw, None, gk, gv, gb, gob, None, None, (dout if (ctx.has_residual and ctx.needs_input_grad[9]) else None)
 
 
 # ======================================================================================================== dense FFN

@@ -234,6 +234,14 @@ def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch
 def combine(y: torch.Tensor, bins: Bins, idx: torch.Tensor, w: torch.Tensor, mode: int, T: int,
             obias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     D = y.shape[1]
+    if residual is not None and residual.dtype == torch.float32 and y.dtype == torch.bfloat16:
+        # fp32 residual stream around bf16 activations (pretrain stack under autocast): fp32 output, no cast passes
+        assert residual.shape == (T, D) and residual.is_contiguous() and obias is None
+        out = torch.empty(T, D, dtype=torch.float32, device=y.device)
+        with _timed("combine", (bins.n * 2 + T * 8) * D + bins.n * 4):
+            L.check(lib.csmoe_combine_mixed(y.data_ptr(), bins.slot_of.data_ptr(), _ptr(idx), w.data_ptr(), residual.data_ptr(),
+                                            out.data_ptr(), T, bins.K, D, mode, _stream()), "combine_mixed")
+        return out
     out = torch.empty(T, D, dtype=y.dtype, device=y.device)
     if residual is not None:
         assert residual.shape == (T, D) and residual.dtype == y.dtype and residual.is_contiguous()
@@ -263,6 +271,44 @@ def layernorm_gate(x2: torch.Tensor, gamma: Optional[torch.Tensor], beta: Option
     return xn, mean, rstd, logits
 
 
+def layernorm_gate_mixed(x2: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,
+                         w_gate: Optional[torch.Tensor] = None):
+    """fp32 x / gamma / beta -> bf16 xn (+ bf16 logits), fp32 mean / rstd -- csmoe_layernorm_gate_mixed."""
+    T, D = x2.shape
+    assert x2.dtype == torch.float32 and (gamma is None or gamma.dtype == torch.float32) and (beta is None or beta.dtype == torch.float32)
+    xn = torch.empty(T, D, dtype=torch.bfloat16, device=x2.device)
+    mean = torch.empty(T, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(T, dtype=torch.float32, device=x2.device)
+    logits, E = None, 0
+    if w_gate is not None:
+        E = w_gate.shape[0]
+        assert w_gate.dtype == torch.bfloat16 and w_gate.is_contiguous() and w_gate.shape[1] == D
+        logits = torch.empty(T, E, dtype=torch.bfloat16, device=x2.device)
+    with _timed("layernorm_gate", T * D * 6):
+        L.check(lib.csmoe_layernorm_gate_mixed(x2.data_ptr(), _ptr(gamma), _ptr(beta), float(eps), xn.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr(), T, D, _ptr(w_gate), _ptr(logits), E, _stream()), "layernorm_gate_mixed")
+    return xn, mean, rstd, logits
+
+
+def layernorm_bwd_mixed(dxn: torch.Tensor, x2: torch.Tensor, gamma: Optional[torch.Tensor], mean: torch.Tensor, rstd: torch.Tensor,
+                        add: Optional[torch.Tensor] = None, want_affine_grads: bool = True, dxn2: Optional[torch.Tensor] = None):
+    """fp32 dx [T,D] (+ fp32 add), dgamma / dbeta [D] fp32 from bf16 gradient stream(s) of xn and fp32 x."""
+    T, D = x2.shape
+    assert dxn.dtype == torch.bfloat16 and x2.dtype == torch.float32 and (add is None or add.dtype == torch.float32)
+    assert dxn2 is None or dxn2.dtype == torch.bfloat16
+    dx = torch.empty_like(x2)
+    nb = int(lib.csmoe_layernorm_bwd_blocks(T))
+    partial = torch.empty(nb, 2 * D, dtype=torch.float32, device=x2.device)
+    with _timed("layernorm_bwd", (8 + 2 + 4 * (add is not None) + 2 * (dxn2 is not None)) * T * D):
+        L.check(lib.csmoe_layernorm_bwd_mixed(dxn.data_ptr(), _ptr(dxn2), x2.data_ptr(), _ptr(gamma), mean.data_ptr(), rstd.data_ptr(),
+                                              _ptr(add), dx.data_ptr(), partial.data_ptr(), T, D, _stream()), "layernorm_bwd_mixed")
+    if not want_affine_grads:
+        return dx, None, None
+    sums = torch.empty(2 * D, dtype=torch.float32, device=x2.device)
+    L.check(lib.csmoe_dense_colsum(partial.data_ptr(), 2 * D, nb, 2 * D, sums.data_ptr(), L.F32, L.F32, _stream()), "layernorm_bwd sums")
+    return dx, sums[:D], sums[D:]
+
+
 def layernorm_bwd(dxn: torch.Tensor, x2: torch.Tensor, gamma: Optional[torch.Tensor], mean: torch.Tensor, rstd: torch.Tensor,
                   add: Optional[torch.Tensor] = None, want_affine_grads: bool = True, dxn2: Optional[torch.Tensor] = None):
     """dx [T,D] (+ add), dgamma [D] fp32, dbeta [D] fp32 -- csmoe_layernorm_bwd + the column sums of its partial rows."""
@@ -280,8 +326,16 @@ def layernorm_bwd(dxn: torch.Tensor, x2: torch.Tensor, gamma: Optional[torch.Ten
     return dx, sums[:D], sums[D:]
 
 
-def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: torch.Tensor, want_dw: bool = True):
+def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: torch.Tensor, want_dw: bool = True, act_dtype=None):
+    """`act_dtype` = dtype of the expert rows when it differs from dout's (fp32 upstream gradient, bf16 rows)."""
     T, D = dout.shape
+    if act_dtype == torch.bfloat16 and dout.dtype == torch.float32:
+        dy = torch.empty(bins.n, D, dtype=torch.bfloat16, device=dout.device)
+        dw = torch.empty(T, bins.K, dtype=torch.float32, device=dout.device) if (want_dw and y is not None) else None
+        with _timed("combine_bwd", (T * 4 + bins.n * 2 * (2 if y is not None else 1)) * D):
+            L.check(lib.csmoe_combine_bwd_mixed(dout.data_ptr(), _ptr(y), bins.slot_of.data_ptr(), w.data_ptr(), dy.data_ptr(), _ptr(dw),
+                                                T, bins.K, D, _stream()), "combine_bwd_mixed")
+        return dy, dw
     dy = torch.empty(bins.n, D, dtype=dout.dtype, device=dout.device)
     dw = torch.empty(T, bins.K, dtype=torch.float32, device=dout.device) if (want_dw and y is not None) else None
     with _timed("combine_bwd", (T + bins.n * (2 if y is not None else 1)) * D * dout.element_size()):

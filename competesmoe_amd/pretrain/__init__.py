@@ -6,6 +6,7 @@ from .moe import MoE
 from .smoe import SMoeLayer
 from .competesmoe import CompeteSMoE
 from .deepseek import DeepSeekV2, DeepSeekV3
+from .block import MoEBlock
 
 __all__ = ["register_moe", "get_moe", "MOE_REGISTRY", "LoggingLayer", "RegularizedLayer", "OncePerIterLayer", "CVMMSel", "cvmm",
-           "cvmm_prepare_sel2", "MoE", "SMoeLayer", "CompeteSMoE", "DeepSeekV2", "DeepSeekV3"]
+           "cvmm_prepare_sel2", "MoE", "SMoeLayer", "CompeteSMoE", "DeepSeekV2", "DeepSeekV3", "MoEBlock"]

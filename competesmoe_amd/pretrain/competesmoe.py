@@ -85,6 +85,11 @@ class CompeteSMoE(MoE):
         return bool(h[self.current_steps - self.step_warm] == 1)
 
     # ------------------------------------------------------------------ policies
+    _fuses_residual = True
+
+    def _plain_gate(self) -> bool:
+        return not (getattr(self.args, "is_cosine", False) or getattr(self.args, "is_norm_weight", False))
+
     def compute_gate(self, x):
         a = self.args
         if getattr(a, "is_cosine", False) and not getattr(a, "is_norm_weight", False):
@@ -101,7 +106,7 @@ class CompeteSMoE(MoE):
             gate_softmax = F.softmax(gate_logits, dim=-1, dtype=torch.float32)
             w, idx = torch.topk(gate_logits, self.num_selected)
             w = torch.sigmoid(w / getattr(self.args, "scale_weight", 1.0))
-            w = w / torch.sum(w, dim=-1, keepdim=True).to(x.dtype)
+            w = w / torch.sum(w, dim=-1, keepdim=True).to(self._stream_dtype or x.dtype)
             return w, idx.int(), gate_softmax, gate_logits
         weights, selected_experts, gate_softmax = self.topk_expert(gate_logits, x.dtype)
         return weights, selected_experts, gate_softmax, gate_logits

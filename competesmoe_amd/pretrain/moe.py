@@ -96,6 +96,16 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         self.dist_experts = None
         self.entropy_expert_selected = []
         self.entropy_expert_all = []
+        # handed over by the block around the layer (pretrain/block.py), each consumed by the next forward
+        self._pre_logits = None       # gate logits computed with the LayerNorm
+        self._residual = None         # the block's residual stream, added in the combine epilogue
+        self._stream_dtype = None     # dtype of the tensor the reference layer would have been called with (its `x.dtype`)
+
+    _fuses_residual = False           # True on layers whose output IS one combine (smoe, competesmoe)
+
+    def _plain_gate(self) -> bool:
+        """compute_gate is F.linear(x, w_gate) (what the block's fused LayerNorm + gate launch computes)."""
+        return True
 
     # ------------------------------------------------------------------ gate / selection
     def gate(self, x):
@@ -104,11 +114,17 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
     def compute_gate(self, x):
         """F.linear(x, w_gate) in the op dtype (logits are bf16 under autocast), HIP skinny GEMM."""
         shp = x.shape
+        pre = self._pre_logits
+        if pre is not None:
+            self._pre_logits = None
+            return pre.view(*shp[:-1], -1)
         op = op_dtype(x)
         lg = GateLogits.apply(x.reshape(-1, shp[-1]).to(op), self.w_gate)
         return lg.view(*shp[:-1], -1)
 
     def select(self, scores, mode, x_dtype):
+        if self._stream_dtype is not None:
+            x_dtype = self._stream_dtype
         shp = scores.shape
         sm, idx, w = RouterSelect.apply(scores.reshape(-1, shp[-1]), self.num_selected, mode, x_dtype == torch.bfloat16)
         K = self.num_selected
@@ -124,10 +140,13 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         op = op_dtype(x)
         x2 = x.reshape(-1, shp[-1]).to(op)
         K = selected_experts.shape[-1]
+        res = None
+        if keys is None and self._residual is not None:
+            res, self._residual = self._residual, None
         out = MoEFFNPacked.apply(x2, weights.reshape(-1, K).float().contiguous(),
                                  selected_experts.reshape(-1, K).int().contiguous(),
                                  self.keys if keys is None else keys, self.values if values is None else values,
-                                 self.bias if bias is None else bias, None, self.act_code, L.COMBINE_DOT)
+                                 self.bias if bias is None else bias, None, self.act_code, L.COMBINE_DOT, res)
         return out.view(*shp[:-1], -1)
 
     def shared_ffn(self, x, keys_shared, values_shared, bias_shared=None):

@@ -6,6 +6,8 @@ from .register import register_moe
 
 @register_moe("smoe")
 class SMoeLayer(MoE):
+    _fuses_residual = True
+
     def forward(self, x, return_id_experts=False, return_full=True, *args, **kwargs):
         gate_logits = self.compute_gate(x)
         weights, selected_experts, gate_softmax = self.topk_expert(gate_logits, x.dtype)

@@ -207,6 +207,25 @@ int csmoe_layernorm_bwd(const void* dxn, const void* dxn2, const void* x, const 
                         const void* add, void* dx, float* partial, int T, int D, int dtype, csmoe_stream_t stream);
 int csmoe_layernorm_bwd_blocks(int T);
 
+/* ---- the same block with an fp32 residual stream around bf16 activations: the pretrain stack under bf16 autocast
+ *      (relative_moe_transformer.py:153-161 inside simple_task.py:295's autocast).  There LayerNorm is an fp32 op on fp32 x with
+ *      fp32 gamma / beta, its output is cast to bf16 by the gate's F.linear (moe.py:121) and by cvmm (cvmm.py:29-32), the bf16 MoE
+ *      output is added to the fp32 residual in fp32 (type promotion), and in the backward autograd casts the fp32 gradient to
+ *      bf16 for the MoE, casts the two bf16 gradients of xn back to fp32 and sums them.  These entries read and write the fp32
+ *      stream directly (no cast passes): xn / logits / y / dy / dxn are bf16, x / residual / out / dout / dx are fp32.
+ *      D <= 4096, D % 8 == 0, 16-byte aligned operands. */
+int csmoe_layernorm_gate_mixed(const float* x, const float* gamma, const float* beta, float eps, void* xn, float* mean, float* rstd,
+                               int T, int D, const void* w_gate, void* logits, int E, csmoe_stream_t stream);
+/* dx = LayerNorm backward of (float(dxn) + float(dxn2)) [+ add], all sums in fp32 */
+int csmoe_layernorm_bwd_mixed(const void* dxn, const void* dxn2, const float* x, const float* gamma, const float* mean,
+                              const float* rstd, const float* add, float* dx, float* partial, int T, int D, csmoe_stream_t stream);
+/* out[t] = float(round_bf16(combine of the bf16 rows y)) + residual[t]   (csmoe_combine with an fp32 residual / output) */
+int csmoe_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const float* residual, float* out,
+                        int T, int K, int D, int mode, csmoe_stream_t stream);
+/* csmoe_combine_bwd with an fp32 upstream gradient, rounded to bf16 on load (the cast autograd would insert) */
+int csmoe_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of, const float* w, void* dy, float* dw, int T, int K,
+                            int D, csmoe_stream_t stream);
+
 /* ---- competition affinity ----------------------------------------------------------------------------
  * aff[r] = mean_d softplus(y[r, d]) rounded to dtype  (competesmoe.py:242; pretrain competesmoe.py:401) and its
  * backward dy[r,d] = round(daff[r] / D * sigmoid(y[r,d])) (+ dy_add if non-null). */

@@ -382,3 +382,13 @@ def pretrain_deepseek_forward(x, w_gate, keys, values, keys_shared, values_share
     one = torch.ones(B, N, 1)
     shared = pretrain_ffn(x, zero, one, keys_shared, values_shared, "relu", op_dtype)
     return out + shared, lg
+
+
+def pretrain_block_forward(x, ln_weight, ln_bias, eps, moe_forward):
+    """The MoE half of RelativeMoeTransformerEncoderLayer.forward, preln (moe_pretrain_model/layers/transformer/
+    relative_moe_transformer.py:153-161 with dropout 0): src + pkm(norm2(src)).  Under bf16 autocast on an fp32 stream LayerNorm
+    stays an fp32 op, `moe_forward(xn)` (a closure over the pretrain_* functions above, which cast to the op dtype like the gate's
+    F.linear and cvmm do) returns bf16, and the sum is fp32 by type promotion.  Returns (src_out, moe_out, xn)."""
+    xn = F.layer_norm(x, (x.shape[-1],), ln_weight, ln_bias, eps)
+    out = moe_forward(xn)
+    return x + out, out, xn

@@ -53,3 +53,38 @@ def test_oracle_block_matches_reference(case, tag):
     assert rel_l2(lnw.grad, fx["ln_grads"]["weight"]) <= 8 * r
     assert rel_l2(lnb.grad, fx["ln_grads"]["bias"]) <= 8 * r
     assert rel_l2(wg.grad, fx["moe_grads"]["gate.weight"]) <= 8 * r + 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ pretrain stack
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["smoe", "competesmoe_router"])
+def test_oracle_pretrain_block_matches_reference(case, tag):
+    """Oracle restatement of the pretrain block against goldens captured from the reference's RelativeMoeTransformerEncoderLayer
+    (tests/golden/make_golden_pretrain_block.py): fp32, and bf16 autocast on an fp32 residual stream."""
+    fx = load(f"pretrain_block_{case}_{tag}")
+    m, st = fx["meta"], fx["state"]
+    op = torch.bfloat16 if m["bf16"] else torch.float32
+    r = 1e-5 if tag == "fp32" else 4e-3
+    x = fx["mid"].clone().requires_grad_(True)
+    lnw = fx["norm2"]["weight"].clone().requires_grad_(True)
+    lnb = fx["norm2"]["bias"].clone().requires_grad_(True)
+    ps = {k: st[k].clone().requires_grad_(True) for k in ("w_gate", "keys", "values")}
+    reg = {}
+
+    def moe(xn):
+        xx = xn.to(op)
+        lg = O.gate_logits(xx, ps["w_gate"].to(op))
+        w, idx, _ = O.router_topk(lg, m["K"], xn.dtype)
+        reg["mlp_ebalance"] = O.entropy_balance(lg) * m["args"]["balance_loss_coef"]
+        return O.pretrain_ffn(xn, idx, w, ps["keys"], ps["values"], "relu", op)
+
+    out, moe_out, xn = O.pretrain_block_forward(x, lnw, lnb, fx["eps"], moe)
+    assert out.dtype == torch.float32 and moe_out.dtype == op and xn.dtype == torch.float32
+    assert rel_l2(out, fx["output"]) <= r, rel_l2(out, fx["output"])
+    assert abs(float(reg["mlp_ebalance"]) - float(fx["reg_loss"]["mlp_ebalance"])) <= 1e-5
+    ((out.float() * fx["dy"]).sum() + reg["mlp_ebalance"].float()).backward()
+    assert rel_l2(x.grad, fx["mid_grad"]) <= 4 * r
+    assert rel_l2(lnw.grad, fx["norm2_grads"]["weight"]) <= 8 * r
+    assert rel_l2(lnb.grad, fx["norm2_grads"]["bias"]) <= 8 * r
+    for k, p in ps.items():
+        assert rel_l2(p.grad, fx["grads"][k]) <= 8 * r + (1e-4 if k == "w_gate" else 0), k

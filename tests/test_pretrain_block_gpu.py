@@ -1,0 +1,209 @@
+"""GPU: the pretrain stack's block around the layer (competesmoe_amd.pretrain.MoEBlock = src + pkm(norm2(src)))
+against goldens captured from the reference's RelativeMoeTransformerEncoderLayer (tests/golden/make_golden_pretrain_block.py), and
+the mixed-precision kernels underneath (fp32 residual stream around bf16 activations) against torch.
+
+fp32 <= 1e-5 (max err / max|ref|); bf16 autocast <= 4e-3 relative L2 on the rows whose routing agrees (CPU-autocast goldens, as in
+tests/test_pretrain_modules_gpu.py)."""
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tests.golden_util import load, rel_l2, max_rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+if torch.cuda.is_available():
+    from competesmoe_amd import ops, _lib as L
+    from competesmoe_amd.pretrain import get_moe, MoEBlock
+
+CASES = ["smoe", "competesmoe_router", "competesmoe_comp", "deepseekv3"]
+
+
+def build(fx, dropout=0.0):
+    m = fx["meta"]
+    args = types.SimpleNamespace(**m["args"])
+    layer = get_moe(m["moe_name"])(m["D"], m["E"], m["F"], n_heads=m["K"], activation=F.relu, log_interval=None, args=args)
+    layer.load_state_dict(fx["state"], strict=True)
+    layer.regularization_present = True
+    kw = {"id_layer": 0}
+    ln = nn.LayerNorm(m["D"], eps=fx["eps"])
+    ln.load_state_dict(fx["norm2"])
+    blk = MoEBlock(ln, layer, dropout).to(DEV).train()
+    if m["moe_name"] == "competesmoe":
+        layer.step_warm, layer.flip_steps = 0, fx["prob_flips"].numel()
+        layer.prob_flips_final = {0: fx["prob_flips"].to(DEV)}
+        layer.set_current_steps(3)
+    return blk, layer, kw
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CASES)
+def test_pretrain_block_matches_reference(case, tag):
+    fx = load(f"pretrain_block_{case}_{tag}")
+    blk, layer, kw = build(fx)
+    bf16 = fx["meta"]["bf16"]
+    comp = fx["meta"]["competition"]
+    x = fx["mid"].to(DEV).requires_grad_(True)
+    dy = fx["dy"].to(DEV)
+    assert blk._fusable(x) or bf16 is None
+    if bf16:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert blk._fusable(x)
+            out = blk(x, **kw)
+            reg = layer.get_reg_loss()
+    else:
+        out = blk(x, **kw)
+        reg = layer.get_reg_loss()
+    assert out.dtype == torch.float32 and out.shape == x.shape
+    assert layer._pre_logits is None and layer._residual is None and layer._stream_dtype is None
+    assert set(reg) == set(fx["reg_loss"])
+    gold = fx["output"].to(DEV)
+    routed_same = True
+    if not bf16:
+        assert max_rel(out, gold) <= 1e-5, max_rel(out, gold)
+    else:
+        # what the layer adds to the stream, row by row (a token routed differently from the reference shows up as ONE bad row)
+        o2 = (out.detach() - x.detach()).reshape(-1, out.shape[-1]).double()
+        g2 = (gold - x.detach()).reshape(-1, out.shape[-1]).double()
+        row_err = (o2 - g2).norm(dim=-1) / (g2.norm(dim=-1) + 1e-12)
+        bad = row_err > 5e-2
+        routed_same = not bool(bad.any())
+        assert bad.float().mean() <= (0.03 if not comp else 0.12), bad.float().mean()
+        assert rel_l2(o2[~bad], g2[~bad]) <= 6e-3, rel_l2(o2[~bad], g2[~bad])
+    for k, v in fx["reg_loss"].items():
+        assert abs(float(reg[k]) - float(v)) <= (2e-6 if not bf16 else (2e-4 if not comp else 2e-3)) + 1e-4 * abs(float(v)), k
+    loss = (out.float() * dy).sum() + sum(v.float() for v in reg.values())
+    loss.backward()
+    if not bf16:
+        assert rel_l2(x.grad, fx["mid_grad"].to(DEV)) <= 4e-5
+        assert rel_l2(blk.norm2.weight.grad, fx["norm2_grads"]["weight"].to(DEV)) <= 4e-5
+        assert rel_l2(blk.norm2.bias.grad, fx["norm2_grads"]["bias"].to(DEV)) <= 4e-5
+        for name, p in layer.named_parameters():
+            g = fx["grads"].get(name)
+            if g is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+                continue
+            assert rel_l2(p.grad, g.to(DEV)) <= 4e-5, (name, rel_l2(p.grad, g.to(DEV)))
+    elif not comp and routed_same:
+        assert x.grad.dtype == torch.float32
+        assert rel_l2(x.grad, fx["mid_grad"].to(DEV)) <= 1e-2
+        assert rel_l2(blk.norm2.weight.grad, fx["norm2_grads"]["weight"].to(DEV)) <= 2e-2
+        assert rel_l2(blk.norm2.bias.grad, fx["norm2_grads"]["bias"].to(DEV)) <= 2e-2
+        for name in ("keys", "values", "w_gate"):
+            assert rel_l2(getattr(layer, name).grad, fx["grads"][name].to(DEV)) <= 2e-2, name
+
+
+# ------------------------------------------------------------------------------------------------ mixed-precision kernels
+@pytest.mark.parametrize("T,D,E", [(1, 8, 2), (37, 64, 8), (300, 1152, 4), (513, 2048, 16), (1024, 4096, 64)])
+def test_layernorm_gate_mixed_vs_torch(T, D, E):
+    torch.manual_seed(T + D)
+    x = torch.randn(T, D, device=DEV) * 1.7 + 0.3
+    g = 1 + 0.1 * torch.randn(D, device=DEV)
+    b = 0.1 * torch.randn(D, device=DEV)
+    wg = (torch.randn(E, D, device=DEV) / D ** 0.5).bfloat16()
+    xn, mean, rstd, logits = ops.layernorm_gate_mixed(x, g, b, 1e-5, wg)
+    ref = F.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-5)
+    assert xn.dtype == torch.bfloat16 and logits.dtype == torch.bfloat16
+    # one rounding of the fp32 result: at most one bf16 ulp from the rounded fp64 result, bit-equal nearly everywhere
+    refb = ref.float().bfloat16()
+    assert (xn != refb).float().mean() <= 2e-3
+    assert float((xn.float() - ref.float()).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+    assert max_rel(mean, x.double().mean(-1)) <= 1e-5 or float(x.double().mean(-1).abs().max()) < 1e-3
+    lref = (xn.float() @ wg.float().t())
+    assert rel_l2(logits, lref) <= 4e-3
+    # no affine parameters
+    xn2, _, _, _ = ops.layernorm_gate_mixed(x, None, None, 1e-5, None)
+    assert rel_l2(xn2, F.layer_norm(x, (D,), None, None, 1e-5)) <= 4e-3
+
+
+@pytest.mark.parametrize("T,D", [(1, 8), (37, 64), (300, 1152), (2050, 2048), (1030, 4096)])
+@pytest.mark.parametrize("two,with_add", [(False, False), (True, True), (False, True)])
+def test_layernorm_bwd_mixed_vs_torch_autograd(T, D, two, with_add):
+    torch.manual_seed(T * 3 + D)
+    x = (torch.randn(T, D, device=DEV) * 1.3).requires_grad_(True)
+    g = (1 + 0.1 * torch.randn(D, device=DEV)).requires_grad_(True)
+    b = (0.1 * torch.randn(D, device=DEV)).requires_grad_(True)
+    d1 = torch.randn(T, D, device=DEV).bfloat16()
+    d2 = torch.randn(T, D, device=DEV).bfloat16() if two else None
+    add = torch.randn(T, D, device=DEV) if with_add else None
+    xn = F.layer_norm(x, (D,), g, b, 1e-5)
+    gsum = d1.float() + (d2.float() if two else 0)
+    xn.backward(gsum)
+    want = x.grad + (add if with_add else 0)
+    with torch.no_grad():
+        _, mean, rstd, _ = ops.layernorm_gate_mixed(x.detach(), g.detach(), b.detach(), 1e-5, None)
+        dx, dg, db = ops.layernorm_bwd_mixed(d1, x.detach(), g.detach(), mean, rstd, add=add, dxn2=d2)
+    assert dx.dtype == torch.float32
+    assert max_rel(dx, want) <= 2e-5, max_rel(dx, want)
+    assert rel_l2(dg, g.grad) <= 2e-5 and rel_l2(db, b.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("T,K,E,D", [(5, 2, 4, 8), (300, 2, 8, 64), (1024, 3, 16, 1152), (2048, 2, 64, 4096)])
+def test_combine_mixed_and_bwd(T, K, E, D):
+    g = torch.Generator().manual_seed(D + T)
+    idx = torch.rand(T, E, generator=g).topk(K, -1).indices.int().to(DEV)
+    bins = ops.bin_tokens(idx, E)
+    y = torch.randn(T * K, D, generator=g).bfloat16().to(DEV)
+    w = torch.rand(T, K, generator=g).to(DEV)
+    res = torch.randn(T, D, generator=g).to(DEV)
+    out = ops.combine(y, bins, idx, w, L.COMBINE_DOT, T, residual=res)
+    assert out.dtype == torch.float32
+    plain = ops.combine(y, bins, idx, w, L.COMBINE_DOT, T)                 # bf16 result of the same combine
+    assert torch.equal(out, res + plain.float())                           # round to bf16, then the fp32 add: exact
+    # backward: fp32 gradient rounded to bf16 on load
+    dout = torch.randn(T, D, generator=g).to(DEV)
+    dy, dw = ops.combine_bwd(dout, y, bins, w, want_dw=True, act_dtype=torch.bfloat16)
+    dy2, dw2 = ops.combine_bwd(dout.bfloat16(), y, bins, w, want_dw=True)
+    assert dy.dtype == torch.bfloat16 and torch.equal(dy, dy2) and torch.equal(dw, dw2)
+
+
+def test_fused_block_equals_unfused_under_autocast():
+    """Same layer, same stream: the fused block against LayerNorm -> layer -> add composed from torch ops around our layer."""
+    torch.manual_seed(5)
+    D, E, Fh, K, B, N = 256, 8, 128, 2, 4, 256
+    args = types.SimpleNamespace(moe_name="smoe", balance_loss_coef=0.01, test_only=False)
+    layer = get_moe("smoe")(D, E, Fh, n_heads=K, activation=F.relu, log_interval=None, args=args).to(DEV).train()
+    layer.regularization_present = True
+    ln = nn.LayerNorm(D).to(DEV)
+    with torch.no_grad():
+        ln.weight.add_(0.1 * torch.randn(D, device=DEV))
+        ln.bias.add_(0.1 * torch.randn(D, device=DEV))
+    blk = MoEBlock(ln, layer, 0.0).train()
+    x = torch.randn(B, N, D, device=DEV)
+    dy = torch.randn(B, N, D, device=DEV)
+    res = []
+    for fused in (True, False):
+        for p in blk.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = blk(xx, id_layer=0) if fused else xx + layer(ln(xx), id_layer=0)
+            reg = sum(layer.get_reg_loss().values())
+        torch.autograd.backward([out, reg.float()], [dy, torch.ones((), device=DEV)])
+        res.append((out.detach(), xx.grad, ln.weight.grad.clone(), layer.keys.grad.clone(), layer.w_gate.grad.clone()))
+    (o1, g1, lw1, k1, wg1), (o2, g2, lw2, k2, wg2) = res
+    assert o1.dtype == o2.dtype == torch.float32
+    # LayerNorm statistics are summed in a different order: xn may differ by one bf16 ulp on a few elements (and a near-tie may
+    # then route a token differently): compare rows, allow a handful of outliers
+    row = ((o1 - o2).double().norm(dim=-1) / ((o2 - x).double().norm(dim=-1) + 1e-12)).flatten()
+    assert (row > 5e-2).float().mean() <= 0.01
+    assert rel_l2(g1, g2) <= 2e-2 and rel_l2(lw1, lw2) <= 2e-2 and rel_l2(k1, k2) <= 2e-2 and rel_l2(wg1, wg2) <= 3e-2
+
+
+def test_block_with_active_dropout_keeps_the_residual_outside():
+    fx = load("pretrain_block_smoe_bf16")
+    blk, layer, kw = build(fx, dropout=0.5)
+    x = fx["mid"].to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = blk(x, **kw)
+    assert out.dtype == torch.float32 and torch.isfinite(out).all()
+    out.sum().backward()
+    assert torch.isfinite(x.grad).all() and layer._residual is None
+    blk.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        o2 = blk(x.detach(), **kw)
+    assert rel_l2(o2, fx["output"].to(DEV)) <= 6e-3
