@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--block-unfused", action="store_true", help="same block composed from torch LayerNorm, the plain layer and a torch add (A/B for --block)")
     ap.add_argument("--stack", default="llava", choices=["llava", "pretrain"], help="pretrain: the LM-pretrain stack's `smoe` layer (packed fp32 master weights keys/values, ReLU, no bias, bf16 autocast: the cvmm path) instead of the LLaVA-stack layer")
     ap.add_argument("--ep-chunks", type=int, default=0, help="expert-parallel runs: groups of local experts whose all-to-all overlaps the grouped GEMMs (competesmoe_amd.ep); 0 = pick the fastest of 1 / 2 / 4 in a short untimed trial before the warmup (1 with a single rank)")
+    ap.add_argument("--ep-trial", action="store_true", help="run the overlap-depth trial even with a single rank (exercises the N>1 control flow on one GPU)")
     ap.add_argument("--force-ep", action="store_true", help="use the expert-parallel layer even with one rank (smoke-tests the N>1 code path)")
     return ap.parse_args()
 
@@ -224,7 +225,7 @@ def main():
 
     ep_tune = None
     if world > 1 or a.force_ep:
-        if a.ep_chunks > 0 or world == 1:
+        if a.ep_chunks > 0 or (world == 1 and not a.ep_trial):
             layer.chunks = max(1, a.ep_chunks)
         else:   # untimed trial: overlap depth that is fastest on THIS node (max over ranks, so every rank picks the same)
             ep_tune = {}

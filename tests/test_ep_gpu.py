@@ -139,7 +139,7 @@ def test_bench_script_runs_small_config_and_ep_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--tokens", "2048", "--seq", "512", "--d-model", "256", "--d-ff", "512",
             "--experts", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    for extra in ([], ["--force-ep"], ["--force-ep", "--ep-chunks", "2"]):
+    for extra in ([], ["--force-ep"], ["--force-ep", "--ep-chunks", "2"], ["--force-ep", "--ep-trial"]):
         env = dict(os.environ, MASTER_PORT=str(_free_port()))
         r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -149,6 +149,8 @@ def test_bench_script_runs_small_config_and_ep_path():
                   "dtype", "data", "config", "roofline"):
             assert k in d, k
         assert d["value"] > 0 and d["n_gpus"] == 1 and d["config"]["workload"]
-        if extra:
+        if "--ep-trial" in extra:          # the N>1 control flow: trial of 1 / 2 / 4 groups, then the chosen depth
+            assert set(d["config"]["ep_chunks_trial_ms"]) == {"1", "2", "4"} and d["config"]["ep_chunks"] in (1, 2, 4)
+        elif extra:
             assert ("ep_wait_exposed" if "--ep-chunks" in extra else "ep_all_to_all") in d["kernels"]
             assert d["config"]["ep_chunks"] == (2 if "--ep-chunks" in extra else 1)
