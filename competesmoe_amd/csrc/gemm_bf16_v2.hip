@@ -16,8 +16,13 @@
 //     SHALLOW: P1 RL(s+1)  P2 RH(s+1)  P3 CL(s+2)  P4 CH(s+2), vmcnt(4) in P4      (2-4 images in flight)
 //     DEEP   : P1 RH(s+1)  P2 RL(s+2)  P3 CL(s+2)  P4 CH(s+2), vmcnt(10) in P1,P2,P4 (5-6 images = 80-96 KiB in flight)
 //     WIDE   : TWO phases of 32 MFMA per K-tile (A: CL,RL,RH x C_lo; B: CH x C_hi), 2 images issued per phase, vmcnt(8)/(6)
-// Measured (profiles/r01): WIDE > DEEP > SHALLOW on every layout (half the barriers: +6..16 %); WIDE is the default,
-// CSMOE_GEMM_SCHED=0|1|2 selects one for A/B runs.
+// Measured (profiles/r01): WIDE > DEEP > SHALLOW on every layout (half the barriers: +6..16 %).
+//     BAL    : WIDE's two phases cut by ROW image instead of by column image (A: CL,CH,RL x R_lo; B: RH x R_hi): 16 + 8 fragment
+//              reads per phase instead of 20 + 4, one image issued in A and three in B, every image two phases ahead
+//     WIDE31 : WIDE with one image issued in phase A and three in phase B
+// Same-box A/B at the headline launches (tools/gemm_bench.py): NT 5.80 / 4.89 ms with BAL against 6.02 / 5.12 (WIDE) and
+// 5.97 / 5.03 (WIDE31); NN 6.03 / 5.19 with BAL against 5.87 / 4.96 (WIDE) and 5.90 / 5.01 (WIDE31).  Default: BAL for NT, WIDE for
+// NN; CSMOE_GEMM_SCHED=1|2|3|4 forces one for A/B runs.
 // Row half 1 (waves 4-7, the SIMD partners of waves 0-3) runs half a phase behind: one hardware barrier is A for one group and
 // B for the other, so one group's ds_reads / DMA issue overlap its partners' MFMAs ("Two waves per SIMD" item 9 of the
 // microarch guide; +9 % here).  Safety under the stagger: reads are retired (lgkmcnt(0)) and the counted vmcnt is taken BEFORE
@@ -38,7 +43,7 @@ constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int CT2_LD = BN2 + 4;              // fp32 epilogue staging row stride (floats); 128 rows per pass
 constexpr int LDS2_BYTES = 128 * CT2_LD * 4; // 133,120 B  (>= 2 * BUF_B = 131,072 B)
 
-enum { SHALLOW = 0, DEEP = 1, WIDE = 2 };
+enum { SHALLOW = 0, DEEP = 1, WIDE = 2, BAL = 3, WIDE31 = 4 };
 
 template <int ROWK, int COLK, int MODE, int SCHED>
 __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
@@ -170,14 +175,106 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   const bool act3 = rows_here > 128 && cols_here > 128;    // C_hi x R_hi
   const bool act4 = rows_here > 128 && cols_here > 0;      // C_lo x R_hi
 
-  if constexpr (SCHED == WIDE) {
+  if constexpr (SCHED == BAL) {
+    // WIDE with the work of the two phases cut by ROW image instead of by column image, so that the LDS reads and the DMA issue
+    // are spread over both phases (WIDE reads 20 fragments in phase A and 4 in phase B):
+    //     phase A: read CL, CH, RL(s)  (16 fragments)   issue RH(s+1)            vmcnt(8)   MFMA C_all x R_lo
+    //     phase B: read RH(s)          ( 8 fragments)   issue CL, CH, RL(s+2)    vmcnt(8)   MFMA C_all x R_hi
+    // An image is waited for one phase before it is read (the counted wait sits in front of barrier A, the staggered half takes
+    // the same wait one hardware barrier later), and a slot is re-filled in the phase after the one that read it.  Issue order
+    // ... [CL,CH,RL](s+1) | RH(s+1) | [CL,CH,RL](s+2) | RH(s+2) ...: vmcnt(8) in A leaves {[CL,CH,RL](s+1), RH(s+1)} in flight
+    // (RH(s) landed), vmcnt(8) in B leaves {RH(s+1), [CL,CH,RL](s+2)} ([CL,CH,RL](s+1) landed).
+    const bool rlo = rows_here > 0, rhi = rows_here > 128, clo = cols_here > 0, chi = cols_here > 128;
+    ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(0); ISSUE_RH(0); ISSUE_CL(1); ISSUE_CH(1); ISSUE_RL(1);
+    WAIT_DMA(8);                                           // CL, CH, RL(0) landed
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < nk; ++s) {
+      const char* base = smem + (s & 1) * (4 * TILE_B);
+      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
+      bf16x8 fc[4][2], fr[4][2];
+      // ---- phase A
+      if (clo && (rlo || rhi)) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
+      }
+      if (chi && (rlo || rhi)) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
+      }
+      if (rlo && clo) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
+      }
+      ISSUE_RH(s + 1);
+      WAIT_DMA(8);                                         // RH(s) landed
+      PHASE_SYNC_IN();
+      if (rlo && clo) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+      }
+      if (rlo && chi) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 2; cb < 4; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+      }
+      PHASE_SYNC_OUT();
+      // ---- phase B
+      if (rhi && clo) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
+      }
+      ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2);
+      WAIT_DMA(8);                                         // CL, CH, RL(s+1) landed
+      PHASE_SYNC_IN();
+      if (rhi && clo) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[cb][4 + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][4 + rb], 0, 0, 0);
+      }
+      if (rhi && chi) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 2; cb < 4; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[cb][4 + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][4 + rb], 0, 0, 0);
+      }
+      PHASE_SYNC_OUT();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
+  } else if constexpr (SCHED == WIDE || SCHED == WIDE31) {
+    // WIDE31: same phases, but phase A (20 fragment reads) issues ONE image and phase B (4 reads) three: A CL(s+1) | B CH(s+1), RL, RH(s+2)
     // TWO phases of 32 MFMA per K-tile (half the barriers of the 4-phase loop; all 8 row blocks stay in registers):
     //     phase A: read CL, RL, RH(s)   issue CL,CH(s+1)   vmcnt(8)   MFMA C_lo x R_all
     //     phase B: read CH(s)           issue RL,RH(s+2)   vmcnt(6)   MFMA C_hi x R_all
     const bool actA = rows_here > 0 && cols_here > 0, actAh = rows_here > 128 && cols_here > 0;
     const bool actB = rows_here > 0 && cols_here > 128, actBh = rows_here > 128 && cols_here > 128;
     ISSUE_RL(0); ISSUE_RH(0); ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(1); ISSUE_RH(1);
-    WAIT_DMA(6);                                           // RL, RH, CL(0) landed
+    WAIT_DMA(6);                                           // RL, RH, CL(0) landed (both orders: 6 instructions behind them)
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
     __builtin_amdgcn_sched_barrier(0);
@@ -204,8 +301,13 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
       }
-      ISSUE_CL(s + 1); ISSUE_CH(s + 1);
-      WAIT_DMA(8);                                         // CH(s) landed
+      if constexpr (SCHED == WIDE31) {
+        ISSUE_CL(s + 1);
+        WAIT_DMA(6);                                       // CH(s) landed: RL, RH(s+1), CL(s+1) may be in flight
+      } else {
+        ISSUE_CL(s + 1); ISSUE_CH(s + 1);
+        WAIT_DMA(8);                                       // CH(s) landed
+      }
       PHASE_SYNC_IN();
       if (actA) {
 #pragma unroll
@@ -233,8 +335,13 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
       }
-      ISSUE_RL(s + 2); ISSUE_RH(s + 2);
-      WAIT_DMA(6);                                         // RL, RH, CL(s+1) landed
+      if constexpr (SCHED == WIDE31) {
+        ISSUE_CH(s + 1); ISSUE_RL(s + 2); ISSUE_RH(s + 2);
+        WAIT_DMA(6);                                       // RL, RH, CL(s+1) landed: CH(s+1), RL, RH(s+2) may be in flight
+      } else {
+        ISSUE_RL(s + 2); ISSUE_RH(s + 2);
+        WAIT_DMA(6);                                       // RL, RH, CL(s+1) landed
+      }
       PHASE_SYNC_IN();
       if (actB) {
 #pragma unroll
@@ -421,13 +528,16 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   }
 }
 
-int sched_pref() {
-  static int v = -1;
-  if (v < 0) {
+// CSMOE_GEMM_SCHED=1|2|3|4 forces DEEP / WIDE / BAL / WIDE31 for every row-space launch (A/B runs); unset = the measured best per
+// layout: BAL for NT (both operands K-contiguous: +4 % over WIDE), WIDE for NN (K-major weights: BAL is 1-4 % slower there).
+int sched_pref(int b_layout) {
+  static int v = -2;
+  if (v == -2) {
     const char* e = getenv("CSMOE_GEMM_SCHED");
-    v = e ? atoi(e) : WIDE;
+    v = e ? atoi(e) : -1;
   }
-  return v;
+  if (v >= 0) return v;
+  return b_layout == CSMOE_B_NK ? BAL : WIDE;
 }
 
 template <typename K>
@@ -456,7 +566,22 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
   if (grid <= 0) return CSMOE_OK;
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_gemm: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;
-  const bool wide = sched_pref() == WIDE;
+  const int sp = sched_pref(b_layout);
+  const bool wide = sp == WIDE;
+#define LAUNCH_SCHED(S)                                                                                              \
+  do {                                                                                                                \
+    if (b_layout == CSMOE_B_NK) {                                                                                     \
+      if ((rc = set_lds2(gg8_kernel<KC, KC, 0, S>))) return rc;                                                       \
+      hipLaunchKernelGGL((gg8_kernel<KC, KC, 0, S>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);             \
+    } else {                                                                                                          \
+      if ((rc = set_lds2(gg8_kernel<KC, KM, 0, S>))) return rc;                                                       \
+      hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, S>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);             \
+    }                                                                                                                 \
+    CSMOE_CHECK_LAUNCH("grouped_gemm(bf16 v2)");                                                                      \
+    return CSMOE_OK;                                                                                                  \
+  } while (0)
+  if (sp == BAL) LAUNCH_SCHED(BAL);
+  if (sp == WIDE31) LAUNCH_SCHED(WIDE31);
   if (b_layout == CSMOE_B_NK) {
     if (wide) {
       if ((rc = set_lds2(gg8_kernel<KC, KC, 0, WIDE>))) return rc;
