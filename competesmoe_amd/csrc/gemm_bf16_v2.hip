@@ -19,10 +19,10 @@
 // Measured (profiles/r01): WIDE > DEEP > SHALLOW on every layout (half the barriers: +6..16 %).
 //     BAL    : WIDE's two phases cut by ROW image instead of by column image (A: CL,CH,RL x R_lo; B: RH x R_hi): 16 + 8 fragment
 //              reads per phase instead of 20 + 4, one image issued in A and three in B, every image two phases ahead
-//     WIDE31 : WIDE with one image issued in phase A and three in phase B
-// Same-box A/B at the headline launches (tools/gemm_bench.py): NT 5.80 / 4.89 ms with BAL against 6.02 / 5.12 (WIDE) and
-// 5.97 / 5.03 (WIDE31); NN 6.03 / 5.19 with BAL against 5.87 / 4.96 (WIDE) and 5.90 / 5.01 (WIDE31).  Default: BAL for NT, WIDE for
-// NN; CSMOE_GEMM_SCHED=1|2|3|4 forces one for A/B runs.
+// Same-box A/B at the headline launches (tools/gemm_bench.py, ms per launch GEMM1 / GEMM2-shaped): NT 5.80 / 4.89 with BAL against
+// 6.02 / 5.12 with WIDE; NN 6.03 / 5.19 with BAL against 5.87 / 4.96 with WIDE.  Default: BAL for NT, WIDE for NN;
+// CSMOE_GEMM_SCHED=1|2|3 forces one for A/B runs.  Two more issue placements were measured and removed: WIDE with one image
+// issued in phase A and three in phase B (NT +1 %, NN -0.5 %), BAL with two images issued in each phase (NT +2 %, NN -3 %).
 // Row half 1 (waves 4-7, the SIMD partners of waves 0-3) runs half a phase behind: one hardware barrier is A for one group and
 // B for the other, so one group's ds_reads / DMA issue overlap its partners' MFMAs ("Two waves per SIMD" item 9 of the
 // microarch guide; +9 % here).  Safety under the stagger: reads are retired (lgkmcnt(0)) and the counted vmcnt is taken BEFORE
@@ -43,7 +43,7 @@ constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int CT2_LD = BN2 + 4;              // fp32 epilogue staging row stride (floats); 128 rows per pass
 constexpr int LDS2_BYTES = 128 * CT2_LD * 4; // 133,120 B  (>= 2 * BUF_B = 131,072 B)
 
-enum { SHALLOW = 0, DEEP = 1, WIDE = 2, BAL = 3, WIDE31 = 4 };
+enum { SHALLOW = 0, DEEP = 1, WIDE = 2, BAL = 3 };
 
 template <int ROWK, int COLK, int MODE, int SCHED>
 __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
@@ -266,15 +266,14 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
       PHASE_SYNC_OUT();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
-  } else if constexpr (SCHED == WIDE || SCHED == WIDE31) {
-    // WIDE31: same phases, but phase A (20 fragment reads) issues ONE image and phase B (4 reads) three: A CL(s+1) | B CH(s+1), RL, RH(s+2)
+  } else if constexpr (SCHED == WIDE) {
     // TWO phases of 32 MFMA per K-tile (half the barriers of the 4-phase loop; all 8 row blocks stay in registers):
     //     phase A: read CL, RL, RH(s)   issue CL,CH(s+1)   vmcnt(8)   MFMA C_lo x R_all
     //     phase B: read CH(s)           issue RL,RH(s+2)   vmcnt(6)   MFMA C_hi x R_all
     const bool actA = rows_here > 0 && cols_here > 0, actAh = rows_here > 128 && cols_here > 0;
     const bool actB = rows_here > 0 && cols_here > 128, actBh = rows_here > 128 && cols_here > 128;
     ISSUE_RL(0); ISSUE_RH(0); ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(1); ISSUE_RH(1);
-    WAIT_DMA(6);                                           // RL, RH, CL(0) landed (both orders: 6 instructions behind them)
+    WAIT_DMA(6);                                           // RL, RH, CL(0) landed
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
     __builtin_amdgcn_sched_barrier(0);
@@ -301,13 +300,8 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
       }
-      if constexpr (SCHED == WIDE31) {
-        ISSUE_CL(s + 1);
-        WAIT_DMA(6);                                       // CH(s) landed: RL, RH(s+1), CL(s+1) may be in flight
-      } else {
-        ISSUE_CL(s + 1); ISSUE_CH(s + 1);
-        WAIT_DMA(8);                                       // CH(s) landed
-      }
+      ISSUE_CL(s + 1); ISSUE_CH(s + 1);
+      WAIT_DMA(8);                                         // CH(s) landed
       PHASE_SYNC_IN();
       if (actA) {
 #pragma unroll
@@ -335,13 +329,8 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
       }
-      if constexpr (SCHED == WIDE31) {
-        ISSUE_CH(s + 1); ISSUE_RL(s + 2); ISSUE_RH(s + 2);
-        WAIT_DMA(6);                                       // RL, RH, CL(s+1) landed: CH(s+1), RL, RH(s+2) may be in flight
-      } else {
-        ISSUE_RL(s + 2); ISSUE_RH(s + 2);
-        WAIT_DMA(6);                                       // RL, RH, CL(s+1) landed
-      }
+      ISSUE_RL(s + 2); ISSUE_RH(s + 2);
+      WAIT_DMA(6);                                         // RL, RH, CL(s+1) landed
       PHASE_SYNC_IN();
       if (actB) {
 #pragma unroll
@@ -528,7 +517,7 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   }
 }
 
-// CSMOE_GEMM_SCHED=1|2|3|4 forces DEEP / WIDE / BAL / WIDE31 for every row-space launch (A/B runs); unset = the measured best per
+// CSMOE_GEMM_SCHED=1|2|3 forces DEEP / WIDE / BAL for every row-space launch (A/B runs); unset = the measured best per
 // layout: BAL for NT (both operands K-contiguous: +4 % over WIDE), WIDE for NN (K-major weights: BAL is 1-4 % slower there).
 int sched_pref(int b_layout) {
   static int v = -2;
@@ -581,7 +570,6 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
     return CSMOE_OK;                                                                                                  \
   } while (0)
   if (sp == BAL) LAUNCH_SCHED(BAL);
-  if (sp == WIDE31) LAUNCH_SCHED(WIDE31);
   if (b_layout == CSMOE_B_NK) {
     if (wide) {
       if ((rc = set_lds2(gg8_kernel<KC, KC, 0, WIDE>))) return rc;

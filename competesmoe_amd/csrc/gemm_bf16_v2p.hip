@@ -234,73 +234,7 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
           acc[(CB0) + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][KS], fr[rb][KS], acc[(CB0) + cb][rb], 0, 0, 0); \
     }
 #define PINNED(X) __builtin_amdgcn_sched_barrier(0); X; __builtin_amdgcn_sched_barrier(0)
-    if constexpr (SCHED == 2) {
-    // BAL with the split DMA placement of SCHED 0: A reads CL, CH, RL(s) (32 transposed reads) and issues nothing in its read
-    // section; RH(s+1) goes between A's MFMAs, CL, CH(s+2) into B's read section (16 reads), RL(s+2) between B's MFMAs.
-    // Issue order ... RH(s) | CL,CH(s+1) | RL(s+1) | RH(s+1) | CL,CH(s+2) | RL(s+2) ...: vmcnt(6) before barrier A of both phases.
-    const bool rlo = rows_here > 0, rhi = rows_here > 128, clo = cols_here > 0, chi = cols_here > 128;
-#define PIECE_RL(tile, j) dma_piece<KM, 2>(dcur.rs_r, SLOT(0, tile), dcur.vb_rl[j], 0, j, (tile) * BK2, cur.red_len, ldr_b, wave)
-#define PIECE_RH(tile, j) dma_piece<KM, 2>(dcur.rs_r, SLOT(3, tile), dcur.vb_rh[j], 0, j, (tile) * BK2, cur.red_len, ldr_b, wave)
-#define MF4(COND, CB, KS, RO)                                                                                               \
-    if (COND) {                                                                                                             \
-      _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                                      \
-        acc[CB][(RO) + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[CB][KS], fr[rb][KS], acc[CB][(RO) + rb], 0, 0, 0);  \
-    }
-    ISSUE_CL(dcur, cur, 1); ISSUE_CH(dcur, cur, 1); ISSUE_RL(dcur, cur, 1);
-    if (first) {
-      WAIT_DMA(6);                                           // all of K-tile 0 landed
-      __builtin_amdgcn_s_barrier();
-    }
-    if (wm == 1) __builtin_amdgcn_s_barrier();               // row half 1 starts half a phase late
-    __builtin_amdgcn_sched_barrier(0);
-    STAMP(1);
-    for (int s = 0; s < nk; ++s) {
-      const char* base = smem + (s & 1) * (4 * TILE_B);
-      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-      bf16x8 fc[4][2], fr[4][2];
-      if (clo && (rlo || rhi)) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_cl, km_c[cb], ks);
-      }
-      if (chi && (rlo || rhi)) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
-      }
-      if (rlo && clo) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_km_raw(i_rl, km_r[rb], ks);
-      }
-      if (s > 0 || first) WAIT_DMA(6);                     // RH(s) landed
-      PHASE_SYNC_IN();
-      MF4(rlo && clo, 0, 0, 0) MF4(rlo && clo, 1, 0, 0)
-      PINNED(PIECE_RH(s + 1, 0));
-      MF4(rlo && chi, 2, 0, 0) MF4(rlo && chi, 3, 0, 0) MF4(rlo && clo, 0, 1, 0) MF4(rlo && clo, 1, 1, 0)
-      PINNED(PIECE_RH(s + 1, 1));
-      MF4(rlo && chi, 2, 1, 0) MF4(rlo && chi, 3, 1, 0)
-      PHASE_SYNC_OUT();
-      if (rhi && clo) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_km_raw(i_rh, km_r[rb], ks);
-      }
-      ISSUE_CL(dcur, cur, s + 2); ISSUE_CH(dcur, cur, s + 2);
-      WAIT_DMA(6);                                         // CL, CH, RL(s+1) landed
-      PHASE_SYNC_IN();
-      MF4(rhi && clo, 0, 0, 4) MF4(rhi && clo, 1, 0, 4)
-      PINNED(PIECE_RL(s + 2, 0));
-      MF4(rhi && chi, 2, 0, 4) MF4(rhi && chi, 3, 0, 4) MF4(rhi && clo, 0, 1, 4) MF4(rhi && clo, 1, 1, 4)
-      PINNED(PIECE_RL(s + 2, 1));
-      MF4(rhi && chi, 2, 1, 4) MF4(rhi && chi, 3, 1, 4)
-      PHASE_SYNC_OUT();
-    }
-    } else if constexpr (SCHED == 1) {
+    if constexpr (SCHED == 1) {
     const bool rlo = rows_here > 0, rhi = rows_here > 128, clo = cols_here > 0, chi = cols_here > 128;
     ISSUE_CL(dcur, cur, 1); ISSUE_CH(dcur, cur, 1); ISSUE_RL(dcur, cur, 1);
     if (first) {
@@ -606,8 +540,9 @@ int set_lds2() {
 int wgrad_sched() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("CSMOE_WGRAD_SCHED");      // A/B: 0 split column-cut phases, 1 BAL, 2 BAL with the split placement
-    v = e ? atoi(e) : 1;                              // same-box: 5.62 / 5.55 / 5.58 ms per headline launch for 0 / 1 / 2
+    const char* e = getenv("CSMOE_WGRAD_SCHED");      // A/B: 0 = column-cut phases with the split DMA placement, 1 = BAL
+    v = e ? atoi(e) : 1;                              // same box: 5.62 (0) / 5.55 (1) ms per headline launch; BAL with RH / RL pieces
+                                                      // moved between the MFMAs like schedule 0 does: 5.58, removed
   }
   return v;
 }
@@ -628,16 +563,15 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_wgrad: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;
   const int ws = wgrad_sched();
-  if ((rc = ws == 2 ? set_lds2<2>() : ws == 1 ? set_lds2<1>() : set_lds2<0>())) return rc;
+  if ((rc = ws == 1 ? set_lds2<1>() : set_lds2<0>())) return rc;
 #ifdef CSMOE_STAMPS
   static unsigned long long* dbg = nullptr;
   if (!dbg) (void)hipMalloc(&dbg, 24 * 16 * 8);
   (void)hipMemsetAsync(dbg, 0, 24 * 16 * 8, st);
   p.aux = dbg;
 #endif
-  if (ws == 2)      hipLaunchKernelGGL(gg8w_kernel<2>, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
-  else if (ws == 1) hipLaunchKernelGGL(gg8w_kernel<1>, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
-  else              hipLaunchKernelGGL(gg8w_kernel<0>, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
+  if (ws == 1) hipLaunchKernelGGL(gg8w_kernel<1>, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
+  else         hipLaunchKernelGGL(gg8w_kernel<0>, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
 #ifdef CSMOE_STAMPS
   {
     static unsigned long long h[24 * 16];
