@@ -387,7 +387,7 @@ class MoEFFNPacked(torch.autograd.Function):
     cast once per call, gradients come back in the master dtype."""
 
     @staticmethod
-    def forward(ctx, x2, w, idx, keys, values, bias, o_bias, act: int, combine_mode: int, residual=None):
+    def forward(ctx, x2, w, idx, keys, values, bias, o_bias, act: int, combine_mode: int, residual=None, stats=None):
         """`residual` [T, Dout] (x2.dtype, or fp32 around bf16 rows): added in the combine epilogue, out = residual + MoE(x2) in
         the residual's dtype -- the block around the layer (pretrain/block.py); its gradient is the upstream gradient itself."""
         x2 = x2.contiguous()
@@ -426,6 +426,8 @@ class MoEFFNPacked(torch.autograd.Function):
         out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, ob, residual=None if residual is None else residual.contiguous(),
                                   before_gemm2=side)
         ctx.has_residual = residual is not None
+        if stats is not None:               # the activated scores, for the caller's `relu_pass_rate` log (moe.py:406-414)
+            stats["hact"] = saved[3]
         ctx.tab, ctx.saved, ctx.w = tab, saved, w
         ctx.keep = (k_op, v_op, b_op)       # keep the cast copies alive: the pointer tables reference them
         ctx.has = (bias is not None, o_bias is not None)
@@ -447,7 +449,7 @@ class MoEFFNPacked(torch.autograd.Function):
                 gb = gb1 if gb1.dtype == ctx.bias_dtype else gb1.to(ctx.bias_dtype)
         if ctx.has[1] and ctx.needs_input_grad[6]:
             gob = _chunked_dense_colsum(dout.contiguous(), ctx.ob_dtype)
-        return dx2, dw, None, gk, gv, gb, gob, None, None, (dout if (ctx.has_residual and ctx.needs_input_grad[9]) else None)
+        return dx2, dw, None, gk, gv, gb, gob, None, None, (dout if (ctx.has_residual and ctx.needs_input_grad[9]) else None), None
 
 
 # ======================================================================================================== dense FFN

@@ -143,10 +143,17 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         res = None
         if keys is None and self._residual is not None:
             res, self._residual = self._residual, None
+        # `relu_pass_rate` every log_interval iterations (compute_scores, moe.py:406-414; upstream tests the bound method
+        # `self.train`, which is always true, so evaluation logs too)
+        stats = {} if (keys is None and self.log_interval is not None and self.iter % self.log_interval == 0) else None
         out = MoEFFNPacked.apply(x2, weights.reshape(-1, K).float().contiguous(),
                                  selected_experts.reshape(-1, K).int().contiguous(),
                                  self.keys if keys is None else keys, self.values if values is None else values,
-                                 self.bias if bias is None else bias, None, self.act_code, L.COMBINE_DOT, res)
+                                 self.bias if bias is None else bias, None, self.act_code, L.COMBINE_DOT, res, stats)
+        if stats:
+            with torch.no_grad():
+                h = stats["hact"]
+                self.log("relu_pass_rate", (h > 0).float().sum() / h.numel())
         return out.view(*shp[:-1], -1)
 
     def shared_ffn(self, x, keys_shared, values_shared, bias_shared=None):

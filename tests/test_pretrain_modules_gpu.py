@@ -134,3 +134,27 @@ def test_cvmm_api_matches_reference_semantics():
     go = torch.autograd.grad(out.sum(), [x, keys, values, w])
     for a, b in zip(go, gr):
         assert max_rel(a, b) <= 5e-5
+
+
+def test_relu_pass_rate_is_logged_every_log_interval():
+    """compute_scores logs the fraction of positive activated scores every `log_interval` iterations (moe.py:406-414)."""
+    fx = load("pretrain_smoe_fp32")
+    m = fx["meta"]
+    args = types.SimpleNamespace(**m["args"])
+    layer = get_moe("smoe")(m["D"], m["E"], m["F"], n_heads=m["K"], activation=F.relu, log_interval=2, args=args)
+    layer.load_state_dict(fx["state"], strict=True)
+    layer = layer.to(DEV).train()
+    x = fx["x"].to(DEV)
+    layer(x)
+    logs = layer.get_logs()
+    assert "relu_pass_rate" in logs
+    # dense reference: scores of the selected experts
+    with torch.no_grad():
+        lg = x @ layer.w_gate.t()
+        idx = lg.softmax(-1).topk(m["K"], -1).indices
+        sc = torch.relu(torch.einsum("btd,btkdf->btkf", x, layer.keys[idx]))
+        want = (sc > 0).float().mean()
+    assert abs(float(logs["relu_pass_rate"]) - float(want)) <= 2e-3
+    layer.iter = 1                      # not a multiple of log_interval: nothing logged
+    layer(x)
+    assert "relu_pass_rate" not in layer.get_logs()
