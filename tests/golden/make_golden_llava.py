@@ -170,6 +170,8 @@ def main():
                  args_kw=dict(hybrid=True))
         run_case(f"smoe_share_{tag}", "smoe_share", dt, K=3)
         run_case(f"deepseekv3_{tag}", "deepseekv3", dt, K=3)
+    # sigmoid-normalised competition scores (competesmoe.py:249-251), fp32
+    run_case("competesmoe_comp_normsigmoid_fp32", "competesmoe", torch.float32, competition=True, args_kw=dict(norm_sigmoid=True))
     schedule_case()
 
 

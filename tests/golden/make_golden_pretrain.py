@@ -249,6 +249,12 @@ def main():
                  args_kw=dict(hybrid=True, balance_affinity=True))
         run_case(f"deepseekv2_{tag}", "deepseekv2", bf16, K=3)
         run_case(f"deepseekv3_{tag}", "deepseekv3", bf16, K=3)
+    # option flags of the pretrain CompeteSMoE (competesmoe.py:435-464, 546-593), fp32
+    run_case("competesmoe_cosine_fp32", "competesmoe", False, competition=False, args_kw=dict(is_cosine=True))
+    run_case("competesmoe_normweight_fp32", "competesmoe", False, competition=False, args_kw=dict(is_norm_weight=True))
+    run_case("competesmoe_normsigmoid_fp32", "competesmoe", False, competition=False, args_kw=dict(norm_sigmoid=True, scale_weight=2.0))
+    run_case("competesmoe_comp_intopk_fp32", "competesmoe", False, competition=True, args_kw=dict(in_topk=True))
+    run_case("competesmoe_comp_tribrid_fp32", "competesmoe", False, competition=True, args_kw=dict(tribrid=True))
     # BASELINE config 1: D=256, E=8, K=2, F=128, T=1024 as [4,256] -- checksums only
     run_case("config1_smoe_fp32", "smoe", False, B=4, N=256, D=256, E=8, F_=128, K=2, full=False)
     cvmm_index_case()

@@ -161,6 +161,11 @@ def test_layer_matches_reference_golden(case, tag):
     assert int((~ok_e).sum()) <= 2 and rel_l2(oe, ge) <= max(rl, 1e-5)
 
 
+def test_competition_with_sigmoid_normalised_scores_matches_golden():
+    """args.norm_sigmoid: top-k and weights from sigmoid(affinity) (competesmoe.py:249-251), golden from the reference class."""
+    test_layer_matches_reference_golden("competesmoe_comp_normsigmoid", "fp32")
+
+
 def test_registry_and_errors():
     from competesmoe_amd.moe import MOE_REGISTRY, register_moe
     assert {"smoe", "competesmoe", "smoe_share", "deepseekv3"} <= set(MOE_REGISTRY)

@@ -107,6 +107,11 @@ def test_llava_competesmoe(case, competing, tag):
     grads_close(fx, named, tag)
 
 
+def test_llava_competesmoe_sigmoid_normalised_scores():
+    """args.norm_sigmoid (competesmoe.py:249-251): golden from the reference class, fp32."""
+    test_llava_competesmoe("competesmoe_comp_normsigmoid", True, "fp32")
+
+
 @pytest.mark.parametrize("tag", TAGS)
 @pytest.mark.parametrize("mode", ["smoe_share", "deepseekv3"])
 def test_llava_shared(mode, tag):
@@ -255,3 +260,57 @@ def test_pretrain_deepseek(mode, tag):
         bad = row_err > 5e-2
         assert bad.float().mean() <= 0.05
         assert rel_l2(o2[~bad], g2[~bad]) <= 8e-3
+
+
+@pytest.mark.parametrize("case", ["competesmoe_cosine", "competesmoe_normweight", "competesmoe_normsigmoid"])
+def test_pretrain_gate_option_flags(case):
+    """Cosine / weight-normalised gate (pretrain competesmoe.py:457-461) and sigmoid-normalised weights (:476-481), router branch,
+    fp32 goldens from the reference class."""
+    import torch.nn.functional as F
+    fx = load(f"pretrain_{case}_fp32")
+    meta, st, a_ = fx["meta"], fx["state"], fx["meta"]["args"]
+    x = fx["x"].clone().requires_grad_(True)
+    ps = {k: st[k].clone().requires_grad_(True) for k in ("w_gate", "keys", "values")}
+    wgt = ps["w_gate"]
+    if a_["is_cosine"]:
+        lg = F.linear(F.normalize(x, p=2.0, dim=-1), F.normalize(wgt, p=2.0, dim=-1))
+    elif a_["is_norm_weight"]:
+        lg = F.linear(x, F.normalize(wgt, p=2.0, dim=-1))
+    else:
+        lg = O.gate_logits(x, wgt)
+    assert rel_l2(lg, fx["gate_logits"]) <= 1e-6
+    if a_["norm_sigmoid"]:
+        w, idx = torch.topk(lg, meta["K"])
+        w = torch.sigmoid(w / a_["scale_weight"])
+        w = w / torch.sum(w, dim=-1, keepdim=True).to(x.dtype)
+    else:
+        w, idx, _ = O.router_topk(lg, meta["K"], x.dtype)
+    out = O.pretrain_ffn(x, idx, w, ps["keys"], ps["values"], "relu", torch.float32)
+    reg = O.entropy_balance(lg) * a_["balance_loss_coef"]
+    assert rel_l2(out, fx["output"]) <= 1e-5
+    assert abs(float(reg) - float(fx["reg_loss"]["mlp_ebalance"])) <= 1e-6
+    ((out * fx["dy"]).sum() + reg).backward()
+    assert rel_l2(x.grad, fx["x_grad"]) <= 4e-5
+    for k, p in ps.items():
+        assert rel_l2(p.grad, fx["grads"][k]) <= 4e-5, k
+
+
+@pytest.mark.parametrize("case", ["competesmoe_comp_intopk", "competesmoe_comp_tribrid"])
+def test_pretrain_router_loss_variants(case):
+    """in_topk / tribrid router losses of the competition branch (pretrain competesmoe.py:546-593), fp32 goldens."""
+    fx = load(f"pretrain_{case}_fp32")
+    meta, st, a_ = fx["meta"], fx["state"], fx["meta"]["args"]
+    x = fx["x"]
+    keys, values, wg = (st[k] for k in ("keys", "values", "w_gate"))
+    lg = O.gate_logits(x, wg)
+    gw, gidx, gsm = O.router_topk(lg, meta["K"], x.dtype)
+    aw, aidx, asm, aff, topk_out = O.pretrain_dense_affinity(x, keys, values, "relu", meta["K"], x.dtype)
+    assert torch.equal(aidx, fx["aff_selected"])
+    if a_["in_topk"]:
+        rl = O.router_loss(torch.gather(gsm, -1, aidx), torch.gather(asm, -1, aidx))
+    else:   # tribrid (without hybrid): full + theta * (affinity top-k + gate top-k)
+        rl = O.router_loss(gsm, asm) + O.router_loss(torch.gather(gsm, -1, aidx), torch.gather(asm, -1, aidx)) * a_["router_theta"]
+        rl = rl + O.router_loss(torch.gather(gsm, -1, gidx), torch.gather(asm, -1, gidx)) * a_["router_theta"]
+    assert abs(float(rl * a_["router_loss_coef"]) - float(fx["reg_loss"]["mlp_router_loss"])) <= 1e-7
+    out = O.pretrain_ffn(x, aidx, aw, keys, values, "relu", torch.float32)
+    assert rel_l2(out, fx["output"]) <= 1e-5

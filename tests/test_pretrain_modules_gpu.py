@@ -87,6 +87,14 @@ def test_pretrain_layer_matches_golden(case, tag):
             assert rel_l2(getattr(layer, name).grad, fx["grads"][name].to(DEV)) <= 2e-2, name
 
 
+@pytest.mark.parametrize("case", ["competesmoe_cosine", "competesmoe_normweight", "competesmoe_normsigmoid", "competesmoe_comp_intopk",
+                                  "competesmoe_comp_tribrid"])
+def test_pretrain_competesmoe_option_flags_match_golden(case):
+    """The option flags of the pretrain CompeteSMoE -- cosine / weight-normalised gate (competesmoe.py:457-461), sigmoid-normalised
+    weights (:476-481), router-loss variants in_topk / tribrid (:546-593) -- against goldens from the reference class, fp32."""
+    test_pretrain_layer_matches_golden(case, "fp32")
+
+
 def test_config1_checksums():
     """BASELINE config 1 (D=256, E=8, K=2, F=128, T=1024 as [4,256]) against reference checksums."""
     fx = load("pretrain_config1_smoe_fp32")
