@@ -194,3 +194,33 @@ def test_schedule_matches_reference_golden():
     assert int(freq.max()) <= a.max_compete_in_iter
     assert layers[0].step_warm == fx["step_warm"] and layers[0].flip_steps == fx["flip_steps"]
     assert layers[2].prob_flips.shape == (fx["flip_steps"],)
+
+
+@pytest.mark.parametrize("reentrant", [False, True])
+@pytest.mark.parametrize("case", ["smoe", "competesmoe_comp", "smoe_share"])
+def test_layer_under_gradient_checkpointing(case, reentrant):
+    """The reference trains with gradient checkpointing (scripts' `--gradient_checkpointing True`): the forward is executed twice
+    per step and routing must be a pure function of (x, parameters, current step).  Outputs and every gradient of a
+    checkpointed call are bit-identical to a plain call."""
+    from torch.utils.checkpoint import checkpoint
+    fx = load(f"llava_{case}_bf16")
+    layer, dt = build_layer(fx)
+    dy = fx["dy"].to(DEV)
+    res = []
+    for use_ckpt in (False, True):
+        for p in layer.parameters():
+            p.grad = None
+        x = fx["x"].to(DEV).requires_grad_(True)
+
+        def run(t):
+            out, aux, _, _ = layer(t)
+            return out, aux
+
+        out, aux = checkpoint(run, x, use_reentrant=reentrant) if use_ckpt else run(x)
+        torch.autograd.backward([out, aux.float()], [dy, torch.ones((), device=DEV)])
+        res.append((out.detach().clone(), float(aux), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None}))
+    (o1, a1, g1, p1), (o2, a2, g2, p2) = res
+    assert torch.equal(o1, o2) and a1 == a2 and torch.equal(g1, g2)
+    assert set(p1) == set(p2)
+    for n in p1:
+        assert torch.equal(p1[n], p2[n]), n
