@@ -1,6 +1,7 @@
 // HBM-bound kernels of the sparse-MoE hot path for gfx950: router selection, token binning, dispatch / combine,
 // bias-gradient column sums and the competition affinity reduction.  One wave (64 lanes) per token row, 16-byte
 // vector accesses, wavefront shuffles for the row reductions / arg-max.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include <algorithm>
@@ -296,6 +297,36 @@ __global__ void __launch_bounds__(256) dispatch_tokens_kernel(const char* x, con
       for (int i = lane; i < nv; i += 64) dst[i] = src[i];
       for (int b = (nv << 4) + lane * 2; b < row_bytes; b += 128)
         *(short*)((char*)dst + b) = *(const short*)((const char*)src + b);
+    }
+  }
+}
+
+// The same with the source row held in registers: up to eight 16-byte loads in flight per lane (one 8 KiB row per wave pass),
+// then K x 8 stores; two loads in flight per lane (the plain loop above) leave an HBM-bound copy at 4.9 TB/s.
+__global__ void __launch_bounds__(256) dispatch_tokens_reg_kernel(const char* x, const int32_t* slot_of, int K, char* xs, int T,
+                                                                  int row_bytes) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  const int nv = row_bytes >> 4;
+  for (int t = wave_g; t < T; t += nw) {
+    const i32x4* src = (const i32x4*)(x + (int64_t)t * row_bytes);
+    for (int c0 = 0; c0 < nv; c0 += 512) {
+      i32x4 r[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int i = c0 + c * 64 + lane;
+        if (i < nv) r[c] = src[i];
+      }
+      for (int k = 0; k < K; ++k) {
+        const int m = slot_of[(int64_t)t * K + k];
+        i32x4* dst = (i32x4*)(xs + (int64_t)m * row_bytes);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int i = c0 + c * 64 + lane;
+          if (i < nv) dst[i] = r[c];
+        }
+      }
     }
   }
 }
@@ -991,6 +1022,7 @@ __global__ void __launch_bounds__(256) expert_order_kernel(const int32_t* offset
   }
 }
 
+// grid-stride row kernels: 4 rows (waves) per workgroup; caps of 2048..16384 workgroups measure the same (tools/hbm_bench.py)
 inline int stride_grid(int rows) { return std::max(1, std::min((rows + 3) / 4, 4096)); }
 
 }  // namespace
@@ -1054,8 +1086,13 @@ int k_dispatch_rows(const void* x, const int32_t* perm, int K, void* xs, int n, 
 
 int k_dispatch_tokens(const void* x, const int32_t* slot_of, int K, void* xs, int T, int row_bytes, int vec_ok, hipStream_t st) {
   if (T == 0) return CSMOE_OK;
-  hipLaunchKernelGGL(dispatch_tokens_kernel, dim3(stride_grid(T)), dim3(256), 0, st, (const char*)x, slot_of, K, (char*)xs, T,
-                     row_bytes, vec_ok);
+  static const bool plain = getenv("CSMOE_DISPATCH_PLAIN") != nullptr;       // A/B switch
+  if (vec_ok && !plain)
+    hipLaunchKernelGGL(dispatch_tokens_reg_kernel, dim3(stride_grid(T)), dim3(256), 0, st, (const char*)x, slot_of, K, (char*)xs, T,
+                       row_bytes);
+  else
+    hipLaunchKernelGGL(dispatch_tokens_kernel, dim3(stride_grid(T)), dim3(256), 0, st, (const char*)x, slot_of, K, (char*)xs, T,
+                       row_bytes, vec_ok);
   CSMOE_CHECK_LAUNCH("dispatch_tokens");
   return CSMOE_OK;
 }
