@@ -31,7 +31,7 @@ def _experts(E, D, F, seed, dt, dev):
     return ex.to(dev).to(dt)
 
 
-def _run(rank, world, port, backend, dt_name, q, chunks=1):
+def _run(rank, world, port, backend, dt_name, q, chunks=1, empty_half=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dev = torch.device("cuda", 0)
@@ -56,7 +56,14 @@ def _run(rank, world, port, backend, dt_name, q, chunks=1):
         local = nn.ModuleList([_experts(E, D, F, 7, dt, dev)[rank * El + i] for i in range(El)])
         epl = ep.EPSMoeLayer(D, D, E, K, local, args, chunks=chunks).to(dev).to(dt).train()
         g = torch.Generator().manual_seed(50 + rank)
-        x = torch.randn(B, N, D, generator=g).to(dt).to(dev)
+        x = torch.randn(B, N, D, generator=g)
+        if empty_half:      # experts E/2 .. E-1 are never selected: whole groups (and, at world 2, a whole rank) receive no rows
+            x[..., 0] = x[..., 0].abs() + 4.0
+            with torch.no_grad():
+                for lay in (full, epl):
+                    lay.gate.weight[: E // 2, 0] = 1.0
+                    lay.gate.weight[E // 2:, 0] = -1.0
+        x = x.to(dt).to(dev)
         dy = torch.randn(B, N, D, generator=g).to(dt).to(dev)
         xa = x.clone().requires_grad_(True)
         xb = x.clone().requires_grad_(True)
@@ -95,11 +102,11 @@ def _run(rank, world, port, backend, dt_name, q, chunks=1):
         dist.destroy_process_group()
 
 
-def _launch(world, backend, dt_name, chunks=1):
+def _launch(world, backend, dt_name, chunks=1, empty_half=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, backend, dt_name, q, chunks)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, backend, dt_name, q, chunks, empty_half)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -128,6 +135,13 @@ def test_ep_chunked_world1_rccl_equals_single_gpu(chunks):
 @pytest.mark.parametrize("dt_name,chunks", [("fp32", 2), ("bf16", 4)])
 def test_ep_chunked_world2_one_gpu_equals_single_gpu(dt_name, chunks):
     assert _launch(2, "gloo", dt_name, chunks) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("world,backend,chunks", [(1, "nccl", 1), (1, "nccl", 2), (2, "gloo", 1), (2, "gloo", 2)])
+def test_ep_with_experts_that_receive_nothing(world, backend, chunks):
+    """Half of the experts are never selected: empty groups of the overlapped exchange, zero-row grouped GEMMs, and (world 2) a
+    rank that receives no rows at all and still takes part in every collective."""
+    assert _launch(world, backend, "fp32", chunks, True) == {r: True for r in range(world)}
 
 
 def test_bench_script_runs_small_config_and_ep_path():
