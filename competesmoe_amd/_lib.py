@@ -8,6 +8,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 and must be loaded FIRST, so that this library's DT_NEEDED entry binds
+# to the runtime instance torch uses (same device context, streams and allocations).  Loaded the other way round the process holds
+# two HIP runtimes and launches from this library fail with "no ROCm-capable device is detected" (seen with build() then smoke()
+# in one process).
+import torch  # noqa: F401  (load order, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSMOE_LIB") or os.path.join(_HERE, "lib", "libcsmoe_hip.so")   # CSMOE_LIB: A/B builds only
 

@@ -148,3 +148,22 @@ def test_quick_gelu_experts_and_unknown_activations(dt):
         e2 = nn.ModuleList([nn.Sequential(nn.Linear(D, F), bad, nn.Linear(F, D)) for _ in range(E)])
         with pytest.raises(NotImplementedError):
             get_moe("smoe")(D, D, E, K, e2, ARGS).to(DEV)(x.float().to(DEV))
+
+
+def test_package_imported_before_torch_uses_torchs_hip_runtime():
+    """A fresh interpreter that imports the package FIRST (what build() followed by smoke() in one process does): the library
+    must bind to the HIP runtime PyTorch ships, not bring a second one (launches then fail with "no ROCm-capable device")."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import competesmoe_amd\n"
+            "import torch\n"
+            "from competesmoe_amd import ops\n"
+            "x = torch.randn(64, 32, device='cuda')\n"
+            "w = torch.randn(8, 32, device='cuda')\n"
+            "lg = ops.gate_logits(x, w)\n"
+            "torch.cuda.synchronize()\n"
+            "assert torch.allclose(lg, x @ w.t(), atol=1e-4)\n"
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
