@@ -1,5 +1,6 @@
 """GPU edge cases of the layer against the CPU oracle: empty batch, a single expert, K == E, every token routed to ONE expert
 (63 empty bins + one ragged maximum-size bin), sizes that are not multiples of any tile, non-contiguous input."""
+import os
 import types
 
 import pytest
