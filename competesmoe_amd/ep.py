@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .functional import ExpertTable, _flip
+from .functional import ExpertTable
 from .moe.moe import MoeLayer
 from .moe.register import register_moe
 

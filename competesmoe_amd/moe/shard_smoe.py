@@ -3,7 +3,6 @@
 aux loss (moe_model/model/moe/deepseekv3.py:12-56 -- not imported by the reference's __init__, registered here)."""
 import copy
 
-import torch
 import torch.nn as nn
 
 from .register import register_moe

@@ -1,5 +1,4 @@
 """`smoe`: softmax -> top-K -> renormalise router + sparse FFN (moe_model/model/moe/smoe.py:11-64)."""
-import torch
 
 from .register import register_moe
 from .moe import MoeLayer

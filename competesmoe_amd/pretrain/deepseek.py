@@ -4,7 +4,6 @@ deepseekv3.py:38-190).  Both add one always-on shared expert `keys_shared [1,D,F
 (n_shared_experts hard-coded 1 upstream)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import _lib as L
 from .moe import MoE

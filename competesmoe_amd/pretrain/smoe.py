@@ -1,5 +1,4 @@
 """Pretrain `smoe` (moe_pretrain_model/layers/moe/smoe.py:38-263)."""
-from .. import _lib as L
 from .moe import MoE
 from .register import register_moe
 

@@ -16,8 +16,7 @@ Gradients come from torch autograd over these differentiable restatements.
 from __future__ import annotations
 
 import math
-from types import SimpleNamespace
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
