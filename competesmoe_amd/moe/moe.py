@@ -11,7 +11,7 @@ What changed underneath: `compute_moe` is one binning pass + dispatch + two grou
 from __future__ import annotations
 
 import copy
-from typing import List, Optional, Tuple
+from typing import List, NamedTuple, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -60,6 +60,14 @@ def parse_expert(expert: nn.Module) -> Tuple[nn.Linear, int, nn.Linear]:
     raise NotImplementedError(
         f"competesmoe_amd: expert module {type(expert).__name__} is not a Linear-act-Linear FFN; the HIP path supports "
         "nn.Sequential(Linear, act, Linear) and modules exposing fc1 / activation_fn / fc2")
+
+
+class Route(NamedTuple):
+    """One routing decision of the gate: x.dtype logits, fp32 softmax, int32 top-K indices, fp32 renormalised weights."""
+    logits: torch.Tensor
+    softmax: torch.Tensor
+    idx: torch.Tensor
+    w: torch.Tensor
 
 
 class MoeLayer(nn.Module):
@@ -166,6 +174,26 @@ class MoeLayer(nn.Module):
         sm, idx, w = RouterSelect.apply(gate_logits.reshape(-1, shp[-1]), K, L.SEL_SOFTMAX,
                                         gate_logits.dtype == torch.bfloat16)
         return w.view(*shp[:-1], K), idx.view(*shp[:-1], K), sm.view(shp)
+
+    # ------------------------------------------------------------------ helpers shared by the sparse layers
+    def _route(self, x) -> "Route":
+        """Gate projection + softmax / top-K / renormalisation (smoe.py:42-44) as one record."""
+        logits = self.gate_logits(x)
+        w, idx, sm = self.topk_expert(gate_logits=logits)
+        return Route(logits, sm, idx, w)
+
+    def _router_aux(self, route: "Route", wanted: bool, like: torch.Tensor, keep_metrics: bool = False):
+        """(auxiliary loss, infor_aux) of a sparse step: balance + z-loss when `wanted` (smoe.py:51-62), else a zero and {}.
+        `keep_metrics` stores the tensors the reference keeps in `log_metrics` for analysis -- as tensors, without its two
+        `.item()` host syncs."""
+        if not wanted:
+            return like.new_zeros(()), {}       # a fill kernel: torch.tensor(0.0, device=...) would be a blocking H2D copy
+        aux, bal, z = self.combine_loss(route.idx, route.softmax, route.logits)
+        infor = {"balance_loss": bal.clone().detach(), "router_z_loss": z.clone().detach()}
+        if keep_metrics:
+            self.log_metrics.update(weights=route.w, balance_loss=infor["balance_loss"], router_z_loss=infor["router_z_loss"],
+                                    gate_softmax=route.softmax, selected_experts=route.idx)
+        return aux, infor
 
     # ------------------------------------------------------------------ expert pointer table
     def _expert_table(self, n_experts: int, dtype, device) -> Tuple[ExpertTable, List[torch.Tensor]]:

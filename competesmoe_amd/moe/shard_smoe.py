@@ -24,24 +24,18 @@ class _SharedBase(MoeLayer):
         self.init_gate_weights()
 
     def _routed_and_shared(self, x):
-        gate_logits = self.gate_logits(x)
-        weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
-        routed = self.compute_moe(selected_experts, weights, None, x, n_experts=self.num_of_experts)
-        shared = self.dense_expert(self.num_of_experts, x)
-        return routed, shared, selected_experts, gate_softmax, gate_logits
+        """(routed output over the E-1 gated experts, dense output of the always-on last expert, the routing record)."""
+        route = self._route(x)
+        routed = self.compute_moe(route.idx, route.w, None, x, n_experts=self.num_of_experts)
+        return routed, self.dense_expert(self.num_of_experts, x), route
 
 
 @register_moe("smoe_share")
 class MoEShareLayer(_SharedBase):
     def forward(self, x, return_id_experts=False, is_vision=False):
-        routed, shared, selected_experts, gate_softmax, gate_logits = self._routed_and_shared(x)
-        output = shared * 0.5 + routed * 0.5
-        auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
-        infor_aux = {}
-        if x.requires_grad:
-            auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(selected_experts, gate_softmax, gate_logits)
-            infor_aux = {"balance_loss": balance_loss.clone().detach(), "router_z_loss": router_z_loss.clone().detach()}
-        return output, auxiliary_loss, None, infor_aux
+        routed, shared, route = self._routed_and_shared(x)
+        aux, infor_aux = self._router_aux(route, x.requires_grad, x)
+        return shared * 0.5 + routed * 0.5, aux, None, infor_aux
 
 
 @register_moe("deepseekv3")
@@ -51,10 +45,8 @@ class DeepSeekV3ShareLayer(_SharedBase):
         self.routed_scaling_factor = 2.5   # declared, unused (deepseekv3.py:21)
 
     def forward(self, x, return_id_experts=False, is_vision=False):
-        routed, shared, selected_experts, gate_softmax, gate_logits = self._routed_and_shared(x)
-        output = shared + routed
-        auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(selected_experts, gate_softmax, gate_logits)
-        infor_aux = {"balance_loss": balance_loss.clone().detach(), "router_z_loss": router_z_loss.clone().detach()}
+        routed, shared, route = self._routed_and_shared(x)
+        aux, infor_aux = self._router_aux(route, True, x)          # this variant computes the losses unconditionally
         if return_id_experts:
-            return output, auxiliary_loss, gate_softmax
-        return output, auxiliary_loss, None, infor_aux
+            return shared + routed, aux, route.softmax
+        return shared + routed, aux, None, infor_aux

@@ -15,19 +15,9 @@ class SMoeLayer(MoeLayer):
         self.init_gate_weights()
 
     def forward(self, x, return_id_experts=False, is_vision=False):
+        """(output, auxiliary_loss, None, infor_aux) -- smoe.py:39-64."""
         self.is_vision = is_vision
-        gate_logits = self.gate_logits(x)
-        weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
-        output = self.compute_moe(selected_experts, weights, None, x)
-        auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
-        infor_aux = {}
-        if x.requires_grad or return_id_experts:
-            auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(selected_experts, gate_softmax, gate_logits)
-            infor_aux = {"balance_loss": balance_loss.clone().detach(), "router_z_loss": router_z_loss.clone().detach()}
-            # kept for analysis like the reference (smoe.py:58-62) but WITHOUT the .item() host syncs
-            self.log_metrics["weights"] = weights
-            self.log_metrics["balance_loss"] = infor_aux["balance_loss"]
-            self.log_metrics["router_z_loss"] = infor_aux["router_z_loss"]
-            self.log_metrics["gate_softmax"] = gate_softmax
-            self.log_metrics["selected_experts"] = selected_experts
-        return output, auxiliary_loss, None, infor_aux
+        route = self._route(x)
+        output = self.compute_moe(route.idx, route.w, None, x)
+        aux, infor_aux = self._router_aux(route, x.requires_grad or return_id_experts, x, keep_metrics=True)
+        return output, aux, None, infor_aux
