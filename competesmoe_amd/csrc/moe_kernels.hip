@@ -454,6 +454,88 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
   }
 }
 
+// K == 2, bf16 rows, D a multiple of 512 (the headline case): the same arithmetic with eight row loads (+ four residual loads) in
+// flight per lane -- four 8-column chunks of both selected rows are fetched before the first add.  The generic kernel above has one
+// dependent load per (chunk, k) in flight and stays at 4.6-5.0 TB/s.
+template <typename TO>
+__global__ void __launch_bounds__(256) combine_k2_kernel(const bf16* y, const int32_t* slot_of, const int32_t* idx, const float* w,
+                                                         const bf16* obias, const TO* add, TO* out, int Tn, int D, int mode) {
+#pragma clang fp contract(off)
+  constexpr bool O32 = std::is_same<TO, float>::value;
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int t = wave_g; t < Tn; t += nw) {
+    // visit order: ascending expert index for the sequential rules (ties: slot order), slot order otherwise -- wave-uniform
+    int s0 = slot_of[(int64_t)t * 2], s1 = slot_of[(int64_t)t * 2 + 1];
+    float w0 = w ? w[(int64_t)t * 2] : 1.f, w1 = w ? w[(int64_t)t * 2 + 1] : 1.f;
+    if (mode != CSMOE_COMBINE_DOT && idx && idx[(int64_t)t * 2 + 1] < idx[(int64_t)t * 2]) {
+      const int si = s0; s0 = s1; s1 = si;
+      const float wi = w0; w0 = w1; w1 = wi;
+    }
+    const bf16* r0 = y + (int64_t)s0 * D;
+    const bf16* r1 = y + (int64_t)s1 * D;
+    for (int dbase = 0; dbase < D; dbase += 4 * 512) {
+      bf16x8 a[4], b[4];
+      float addv[4][8];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d0 = dbase + c * 512 + lane * 8;
+        if (d0 < D) {
+          a[c] = *(const bf16x8*)(r0 + d0);
+          b[c] = *(const bf16x8*)(r1 + d0);
+          if (add) {
+            const TO* arow = add + (int64_t)t * D + d0;
+            if constexpr (O32) {
+              const f32x4 ra = *(const f32x4*)arow, rb = *(const f32x4*)(arow + 4);
+#pragma unroll
+              for (int v = 0; v < 4; ++v) { addv[c][v] = ra[v]; addv[c][4 + v] = rb[v]; }
+            } else {
+              const bf16x8 r8 = *(const bf16x8*)arow;
+#pragma unroll
+              for (int v = 0; v < 8; ++v) addv[c][v] = (float)r8[v];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d0 = dbase + c * 512 + lane * 8;
+        if (d0 >= D) continue;
+        float acc[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const float ya = (float)a[c][v], yb = (float)b[c][v];
+          float r;
+          if (mode == CSMOE_COMBINE_DOT) {
+            r = DT<bf16>::rnd(fmaf(w1, yb, fmaf(w0, ya, 0.f)));
+          } else {
+            float p0 = w0 * ya, p1 = w1 * yb;
+            if (mode == CSMOE_COMBINE_SEQ_RW) { p0 = DT<bf16>::rnd(p0); p1 = DT<bf16>::rnd(p1); }
+            float s = 0.f + p0;
+            s = DT<bf16>::rnd(s);
+            s = s + p1;
+            r = DT<bf16>::rnd(s);
+          }
+          if (obias) r = DT<bf16>::rnd(r + (float)obias[d0 + v]);
+          if (add) r = DT<TO>::rnd(r + addv[c][v]);
+          acc[v] = r;
+        }
+        TO* o = out + (int64_t)t * D + d0;
+        if constexpr (O32) {
+          *(f32x4*)o = f32x4{acc[0], acc[1], acc[2], acc[3]};
+          *(f32x4*)(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        } else {
+          bf16x8 o8;
+#pragma unroll
+          for (int v = 0; v < 8; ++v) o8[v] = (bf16)acc[v];
+          *(bf16x8*)o = o8;
+        }
+      }
+    }
+  }
+}
+
 // combine backward: one wave per TOKEN, inner loop over its K slots (dout[t] comes from L1/L2 after the first slot, so HBM
 // reads it once): dy[slot] = round(w * dout[t]), dw[t,k] = <dout[t], y[slot]>
 // TG = type of the upstream gradient: T, or float with T = bf16 (fp32 residual stream: autograd casts the gradient to bf16 first,
@@ -1102,8 +1184,12 @@ int k_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const f
   if (T == 0) return CSMOE_OK;
   dim3 grid(stride_grid(T)), block(256);
   const bool al = (((uintptr_t)y | (uintptr_t)out | (uintptr_t)obias | (uintptr_t)add) & 15) == 0;
+  static const bool generic_only = getenv("CSMOE_COMBINE_GENERIC") != nullptr;       // A/B switch
   if (dtype == CSMOE_BF16) {
-    if (D % 8 == 0 && al)
+    if (K == 2 && D % 512 == 0 && al && !generic_only)
+      hipLaunchKernelGGL((combine_k2_kernel<bf16>), grid, block, 0, st, (const bf16*)y, slot_of, idx, w, (const bf16*)obias,
+                         (const bf16*)add, (bf16*)out, T, D, mode);
+    else if (D % 8 == 0 && al)
       hipLaunchKernelGGL((combine_kernel<bf16, 8>), grid, block, 0, st, (const bf16*)y, slot_of, idx, w, (const bf16*)obias,
                          (const bf16*)add, (bf16*)out, T, K, D, mode);
     else
@@ -1150,8 +1236,13 @@ int k_combine_bwd(const void* dout, const void* y, const int32_t* perm, const fl
 int k_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const float* add, float* out, int T, int K,
                     int D, int mode, hipStream_t st) {
   if (T == 0) return CSMOE_OK;
-  hipLaunchKernelGGL((combine_kernel<bf16, 8, float>), dim3(stride_grid(T)), dim3(256), 0, st, (const bf16*)y, slot_of, idx, w,
-                     (const bf16*)nullptr, add, out, T, K, D, mode);
+  static const bool generic_only = getenv("CSMOE_COMBINE_GENERIC") != nullptr;
+  if (K == 2 && D % 512 == 0 && !generic_only)
+    hipLaunchKernelGGL((combine_k2_kernel<float>), dim3(stride_grid(T)), dim3(256), 0, st, (const bf16*)y, slot_of, idx, w,
+                       (const bf16*)nullptr, add, out, T, D, mode);
+  else
+    hipLaunchKernelGGL((combine_kernel<bf16, 8, float>), dim3(stride_grid(T)), dim3(256), 0, st, (const bf16*)y, slot_of, idx, w,
+                       (const bf16*)nullptr, add, out, T, K, D, mode);
   CSMOE_CHECK_LAUNCH("combine_mixed");
   return CSMOE_OK;
 }
