@@ -22,7 +22,8 @@
 // Same-box A/B at the headline launches (tools/gemm_bench.py, ms per launch GEMM1 / GEMM2-shaped): NT 5.80 / 4.89 with BAL against
 // 6.02 / 5.12 with WIDE; NN 6.03 / 5.19 with BAL against 5.87 / 4.96 with WIDE.  Default: BAL for NT, WIDE for NN;
 // CSMOE_GEMM_SCHED=1|2|3 forces one for A/B runs.  Two more issue placements were measured and removed: WIDE with one image
-// issued in phase A and three in phase B (NT +1 %, NN -0.5 %), BAL with two images issued in each phase (NT +2 %, NN -3 %).
+// issued in phase A and three in phase B (NT +1 %, NN -0.5 %), BAL with two images issued in each phase (NT +2 %, NN -3 %), BAL with
+// all four images issued in phase B (RH one phase ahead only: NT -1 %, NN -6 %).
 // Row half 1 (waves 4-7, the SIMD partners of waves 0-3) runs half a phase behind: one hardware barrier is A for one group and
 // B for the other, so one group's ds_reads / DMA issue overlap its partners' MFMAs ("Two waves per SIMD" item 9 of the
 // microarch guide; +9 % here).  Safety under the stagger: reads are retired (lgkmcnt(0)) and the counted vmcnt is taken BEFORE
