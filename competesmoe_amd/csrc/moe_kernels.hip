@@ -1107,6 +1107,66 @@ __global__ void __launch_bounds__(256) expert_order_kernel(const int32_t* offset
 // grid-stride row kernels: 4 rows (waves) per workgroup; caps of 2048..16384 workgroups measure the same (tools/hbm_bench.py)
 inline int stride_grid(int rows) { return std::max(1, std::min((rows + 3) / 4, 4096)); }
 
+// combine backward for K == 2, bf16 rows, D a multiple of 512: the upstream-gradient chunk and both y chunks of four 8-column
+// chunks (12 loads) are in flight per lane before the first store; same per-lane accumulation order of the dot products as the
+// generic kernel (bit-identical dw).
+template <typename TG>
+__global__ void __launch_bounds__(256) combine_bwd_k2_kernel(const TG* dout, const bf16* y, const int32_t* slot_of, const float* w,
+                                                             bf16* dy, float* dw, int Tn, int D) {
+  constexpr bool G32 = std::is_same<TG, float>::value;
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  for (int t = wave_g; t < Tn; t += nw) {
+    const int m0 = slot_of[(int64_t)t * 2], m1 = slot_of[(int64_t)t * 2 + 1];
+    const float w0 = w ? w[(int64_t)t * 2] : 1.f, w1 = w ? w[(int64_t)t * 2 + 1] : 1.f;
+    float dot0 = 0.f, dot1 = 0.f;
+    for (int dbase = 0; dbase < D; dbase += 4 * 512) {
+      float gv[4][8];
+      bf16x8 ya[4], yb[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d0 = dbase + c * 512 + lane * 8;
+        if (d0 < D) {
+          const TG* g = dout + (int64_t)t * D + d0;
+          if constexpr (G32) {
+            const f32x4 ga = *(const f32x4*)g, gb = *(const f32x4*)(g + 4);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { gv[c][v] = DT<bf16>::rnd(ga[v]); gv[c][4 + v] = DT<bf16>::rnd(gb[v]); }
+          } else {
+            const bf16x8 g8 = *(const bf16x8*)g;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) gv[c][v] = (float)g8[v];
+          }
+          if (y) {
+            ya[c] = *(const bf16x8*)(y + (int64_t)m0 * D + d0);
+            yb[c] = *(const bf16x8*)(y + (int64_t)m1 * D + d0);
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d0 = dbase + c * 512 + lane * 8;
+        if (d0 >= D) continue;
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { o0[v] = (bf16)(gv[c][v] * w0); o1[v] = (bf16)(gv[c][v] * w1); }
+        *(bf16x8*)(dy + (int64_t)m0 * D + d0) = o0;
+        *(bf16x8*)(dy + (int64_t)m1 * D + d0) = o1;
+        if (y) {
+#pragma unroll
+          for (int v = 0; v < 8; ++v) { dot0 = fmaf(gv[c][v], (float)ya[c][v], dot0); dot1 = fmaf(gv[c][v], (float)yb[c][v], dot1); }
+        }
+      }
+    }
+    if (y && dw) {
+      dot0 = wave_sum(dot0);
+      dot1 = wave_sum(dot1);
+      if (lane == 0) { dw[(int64_t)t * 2] = dot0; dw[(int64_t)t * 2 + 1] = dot1; }
+    }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ host launchers
@@ -1213,8 +1273,12 @@ int k_combine_bwd(const void* dout, const void* y, const int32_t* perm, const fl
   if (n == 0) return CSMOE_OK;
   dim3 grid(stride_grid(n)), block(256);
   const bool al = (((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0;
+  static const bool generic_only = getenv("CSMOE_COMBINE_GENERIC") != nullptr;       // A/B switch
   if (dtype == CSMOE_BF16) {
-    if (D % 8 == 0 && al)
+    if (K == 2 && D % 512 == 0 && al && !generic_only)
+      hipLaunchKernelGGL((combine_bwd_k2_kernel<bf16>), grid, block, 0, st, (const bf16*)dout, (const bf16*)y, perm, w, (bf16*)dy,
+                         dw, n, D);
+    else if (D % 8 == 0 && al)
       hipLaunchKernelGGL((combine_bwd_kernel<bf16, 8>), grid, block, 0, st, (const bf16*)dout, (const bf16*)y, perm, w, (bf16*)dy,
                          dw, n, K, D);
     else
@@ -1250,8 +1314,13 @@ int k_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* idx, c
 int k_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of, const float* w, void* dy, float* dw, int T, int K,
                         int D, hipStream_t st) {
   if (T == 0) return CSMOE_OK;
-  hipLaunchKernelGGL((combine_bwd_kernel<bf16, 8, float>), dim3(stride_grid(T)), dim3(256), 0, st, dout, (const bf16*)y, slot_of, w,
-                     (bf16*)dy, dw, T, K, D);
+  static const bool generic_only = getenv("CSMOE_COMBINE_GENERIC") != nullptr;
+  if (K == 2 && D % 512 == 0 && !generic_only)
+    hipLaunchKernelGGL((combine_bwd_k2_kernel<float>), dim3(stride_grid(T)), dim3(256), 0, st, dout, (const bf16*)y, slot_of, w,
+                       (bf16*)dy, dw, T, D);
+  else
+    hipLaunchKernelGGL((combine_bwd_kernel<bf16, 8, float>), dim3(stride_grid(T)), dim3(256), 0, st, dout, (const bf16*)y, slot_of, w,
+                       (bf16*)dy, dw, T, K, D);
   CSMOE_CHECK_LAUNCH("combine_bwd_mixed");
   return CSMOE_OK;
 }

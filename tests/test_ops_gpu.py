@@ -496,3 +496,55 @@ def test_router_aux_matches_torch_autograd(dt, B, N, E, K):
     # balance alone
     b2, z2 = RouterAux.apply(None, sm.view(B, N, E), idx)
     assert float(b2) == float(bal) and float(z2) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ K = 2 fast paths
+_K2_SCRIPT = r"""
+import sys, torch
+from competesmoe_amd import ops, _lib as L
+T, K, E, D = 1500, 2, 16, 1024
+g = torch.Generator().manual_seed(11)
+idx = torch.rand(T, E, generator=g).topk(K, -1).indices.int().cuda()
+b = ops.bin_tokens(idx, E)
+y = torch.randn(T * K, D, generator=g).bfloat16().cuda()
+w = torch.rand(T, K, generator=g).cuda()
+res = torch.randn(T, D, generator=g).bfloat16().cuda()
+res32 = torch.randn(T, D, generator=g).cuda()
+ob = torch.randn(D, generator=g).bfloat16().cuda()
+dout = torch.randn(T, D, generator=g).bfloat16().cuda()
+dout32 = torch.randn(T, D, generator=g).cuda()
+out = {}
+for mode in (0, 1, 2):
+    out[f"c{mode}"] = ops.combine(y, b, idx, w, mode, T)
+    out[f"c{mode}_res"] = ops.combine(y, b, idx, w, mode, T, residual=res)
+out["c1_ob"] = ops.combine(y, b, idx, w, 1, T, obias=ob)
+out["c1_res32"] = ops.combine(y, b, idx, w, 1, T, residual=res32)
+out["gather_sum"] = ops.dispatch_rows_bwd(y, b, T)
+out["gather_sum_add"] = ops.dispatch_rows_bwd(y, b, T, add=res)
+out["dy"], out["dw"] = ops.combine_bwd(dout, y, b, w)
+out["dy_nody"], _ = ops.combine_bwd(dout, None, b, w, want_dw=False)
+out["dy32"], out["dw32"] = ops.combine_bwd(dout32, y, b, w, act_dtype=torch.bfloat16)
+torch.cuda.synchronize()
+torch.save({k: v.cpu() for k, v in out.items()}, sys.argv[1])
+"""
+
+
+def test_k2_fast_kernels_are_bit_identical_to_the_generic_ones(tmp_path):
+    """combine_k2_kernel / combine_bwd_k2_kernel (K = 2, D % 512 == 0) against the generic kernels (CSMOE_COMBINE_GENERIC=1 in a
+    second process), every rounding rule, bias / residual (bf16 and fp32) variants, bf16 and fp32 upstream gradients."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (("fast", {}), ("generic", {"CSMOE_COMBINE_GENERIC": "1"})):
+        f = str(tmp_path / f"{tag}.pt")
+        env = dict(os.environ, **extra)
+        env.pop("CSMOE_COMBINE_GENERIC", None) if not extra else None
+        r = subprocess.run([sys.executable, "-c", _K2_SCRIPT, f], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(torch.load(f, weights_only=True))
+    fast, gen = outs
+    assert set(fast) == set(gen)
+    for k in fast:
+        assert torch.equal(fast[k], gen[k]), k
