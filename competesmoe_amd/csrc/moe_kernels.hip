@@ -274,7 +274,19 @@ __global__ void __launch_bounds__(256) dispatch_rows_kernel(const char* x, const
     const int t = perm[m] / K;
     const i32x4* src = (const i32x4*)(x + (int64_t)t * row_bytes);
     i32x4* dst = (i32x4*)(xs + (int64_t)m * row_bytes);
-    for (int i = lane; i < nv; i += 64) dst[i] = src[i];
+    for (int c0 = 0; c0 < nv; c0 += 512) {           // eight 16-byte loads in flight per lane, then the stores
+      i32x4 r[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int i = c0 + c * 64 + lane;
+        if (i < nv) r[c] = src[i];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int i = c0 + c * 64 + lane;
+        if (i < nv) dst[i] = r[c];
+      }
+    }
     // tail (row_bytes not a multiple of 16): 2-byte granularity
     for (int b = (nv << 4) + lane * 2; b < row_bytes; b += 128)
       *(short*)((char*)dst + b) = *(const short*)((const char*)src + b);
