@@ -6,6 +6,7 @@ Reference parity notes are on each class (file:line of the reference code whose 
 from __future__ import annotations
 
 import os
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -247,6 +248,38 @@ class ExpertTable:
     param_dtype: torch.dtype = torch.float32   # dtype of the gradients handed back
 
 
+# Operand-dtype copies of fp32 master weights kept across calls while the parameter is unchanged (same storage, same autograd
+# version counter: every in-place update through torch bumps it).  The reference's pretrain task runs several micro-batches per
+# optimizer step (simple_task.py:286-320) and evaluates between steps: all but the first forward after an update then skip the
+# HBM-bound cast (34.5 GB at the headline shape).  Opt-in -- CSMOE_WEIGHT_CACHE=1 or `weight_cache(True)` -- because it holds one
+# bf16 copy of the expert weights per layer for as long as the layer lives, and because a writer that goes around torch (a raw
+# pointer write from another library) would not be seen.
+_WEIGHT_CACHE_ON = os.environ.get("CSMOE_WEIGHT_CACHE", "0") == "1"
+_WEIGHT_CACHE = {}
+
+
+def weight_cache(enabled: bool) -> None:
+    global _WEIGHT_CACHE_ON
+    _WEIGHT_CACHE_ON = bool(enabled)
+    if not enabled:
+        _WEIGHT_CACHE.clear()
+
+
+def _cached_copy(t: torch.Tensor, op):
+    """(operand copy of parameter t, hit) from the cache: the SAME tensor object (a freed parameter's address can be handed to a new
+    one), unchanged since the copy was made."""
+    ent = _WEIGHT_CACHE.get((t.data_ptr(), op))
+    if ent is not None and ent[0]() is t and ent[1] == t._version and ent[2].shape == t.shape:
+        return ent[2], True
+    return None, False
+
+
+def _remember(t: torch.Tensor, op, copy: torch.Tensor) -> None:
+    for k in [k for k, e in _WEIGHT_CACHE.items() if e[0]() is None]:       # parameters that no longer exist
+        del _WEIGHT_CACHE[k]
+    _WEIGHT_CACHE[(t.data_ptr(), op)] = (weakref.ref(t), t._version, copy)
+
+
 _CAST_OVERLAP = os.environ.get("CSMOE_CAST_OVERLAP", "1") != "0"
 _SIDE_STREAMS = {}
 
@@ -395,9 +428,20 @@ class MoEFFNPacked(torch.autograd.Function):
         E, D, F = keys.shape
         Dout = values.shape[2]
         dev = x2.device
-        k_op = keys.contiguous() if keys.dtype == op else keys.to(op)
+        k_hit = v_hit = False
+        k_op = v_op = None
+        if _WEIGHT_CACHE_ON and keys.dtype != op:
+            k_op, k_hit = _cached_copy(keys, op)
+        if _WEIGHT_CACHE_ON and values.dtype != op:
+            v_op, v_hit = _cached_copy(values, op)
+        if not k_hit:
+            k_op = keys.contiguous() if keys.dtype == op else keys.to(op)
+            if _WEIGHT_CACHE_ON and keys.dtype != op:
+                _remember(keys, op, k_op)
         side = None
-        if values.dtype == op:
+        if v_hit:
+            pass
+        elif values.dtype == op:
             v_op = values.contiguous()
         elif _CAST_OVERLAP and values.is_contiguous() and values.numel() >= (1 << 24):
             # fp32 master -> bf16 operand cast of `values` (HBM-bound) on a side stream, under the first grouped GEMM (MFMA-bound),
@@ -410,6 +454,8 @@ class MoEFFNPacked(torch.autograd.Function):
                 v_op.copy_(values)
         else:
             v_op = values.to(op)
+        if _WEIGHT_CACHE_ON and not v_hit and values.dtype != op:
+            _remember(values, op, v_op)
         es = k_op.element_size()
         ar = ops.cached_arange(E, dev)
         b_op = None

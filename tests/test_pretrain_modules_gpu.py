@@ -166,3 +166,35 @@ def test_relu_pass_rate_is_logged_every_log_interval():
     layer.iter = 1                      # not a multiple of log_interval: nothing logged
     layer(x)
     assert "relu_pass_rate" not in layer.get_logs()
+
+
+def test_operand_weight_cache_skips_casts_until_the_weights_change():
+    """Opt-in cache of the bf16 operand copies of fp32 master weights (micro-batches of one optimizer step, evaluation): same
+    outputs as without it, no new copy while the parameters are unchanged, a fresh one after an in-place update."""
+    from competesmoe_amd import functional as Fn
+    fx = load("pretrain_smoe_bf16")
+    layer, kw = build(fx)
+    x = fx["x"].to(DEV)
+
+    def run():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return layer(x, **kw).detach().clone()
+
+    ref = run()
+    Fn.weight_cache(True)
+    try:
+        a = run()
+        ents = {k: e[2].data_ptr() for k, e in Fn._WEIGHT_CACHE.items()}
+        assert len(ents) == 2                               # keys and values
+        b = run()
+        assert {k: e[2].data_ptr() for k, e in Fn._WEIGHT_CACHE.items()} == ents       # reused, not re-cast
+        assert torch.equal(a, ref) and torch.equal(b, ref)
+        with torch.no_grad():
+            layer.keys.mul_(0.5)                            # an optimizer step: in-place, bumps the version counter
+        c = run()
+        assert not torch.equal(c, ref)
+        Fn.weight_cache(False)
+        assert torch.equal(run(), c)                        # what the uncached path computes from the updated weights
+    finally:
+        Fn.weight_cache(False)
+    assert not Fn._WEIGHT_CACHE
