@@ -508,7 +508,19 @@ class DenseFFN(torch.autograd.Function):
     def forward(ctx, x2, w1, b1, w2, b2, act: int, layout: int):
         x2 = x2.contiguous()
         op = x2.dtype
-        cast = lambda t: None if t is None else (t.contiguous() if t.dtype == op else t.to(op))
+        def cast(t):
+            if t is None:
+                return None
+            if t.dtype == op:
+                return t.contiguous()
+            if _WEIGHT_CACHE_ON:
+                c, hit = _cached_copy(t, op)
+                if not hit:
+                    c = t.to(op)
+                    _remember(t, op, c)
+                return c
+            return t.to(op)
+
         w1o, b1o, w2o, b2o = cast(w1), cast(b1), cast(w2), cast(b2)
         hpre, hact = ops.dense_gemm(x2, w1o, layout, bias=b1o, epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True)
         y = ops.dense_gemm(hact, w2o, layout, bias=b2o, epilogue=L.EPI_BIAS if b2o is not None else L.EPI_PLAIN)
