@@ -3,6 +3,7 @@ against fp64 torch references: ragged / empty experts, N and K that fit no tile,
 fp32 gradient outputs, accumulate, dealt and contiguous XCD order.  Shapes are drawn so that the v2 kernels are the ones that run
 (N >= 256, K >= 128, M >= 2048 / Na, Nb >= 256, M >= 512)."""
 import math
+import os
 import random
 
 import pytest
@@ -28,7 +29,11 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("i,E,M,N,Kd,b_layout,epi,act", _cases(16, 1234))
+N_ROW = int(os.environ.get("CSMOE_FUZZ_CASES", "16"))      # a one-off long sweep: CSMOE_FUZZ_CASES=300
+N_WGRAD = int(os.environ.get("CSMOE_FUZZ_CASES", "14"))
+
+
+@pytest.mark.parametrize("i,E,M,N,Kd,b_layout,epi,act", _cases(N_ROW, 1234))
 def test_rowspace_fuzz(i, E, M, N, Kd, b_layout, epi, act):
     g = torch.Generator().manual_seed(1000 + i)
     off = make_groups(E, M, seed=i, empty=E > 2)
@@ -59,7 +64,7 @@ def _wcases(n, seed):
              rng.choice([torch.bfloat16, torch.float32]), rng.choice([False, True]), rng.choice([False, True])) for i in range(n)]
 
 
-@pytest.mark.parametrize("i,E,M,Na,Nb,out_dtype,accumulate,dealt", _wcases(14, 99))
+@pytest.mark.parametrize("i,E,M,Na,Nb,out_dtype,accumulate,dealt", _wcases(N_WGRAD, 99))
 def test_wgrad_fuzz(i, E, M, Na, Nb, out_dtype, accumulate, dealt):
     g = torch.Generator().manual_seed(2000 + i)
     off = make_groups(E, M, seed=50 + i, empty=E > 2).to(DEV)
