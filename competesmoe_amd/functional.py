@@ -309,6 +309,28 @@ def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residua
     return out, (bins, xs, hpre, hact, y)
 
 
+_WGRAD_SPLIT = os.environ.get("CSMOE_WGRAD_SPLIT", "1") != "0"       # A/B switch
+
+
+def _grouped_wgrad(a: torch.Tensor, b: torch.Tensor, bins, E: int, pd) -> torch.Tensor:
+    """out[e] = a_e^T @ b_e -> [E, Na, Nb] in dtype pd.  E * ceil(Na/256) * ceil(Nb/256) output tiles: 340 at the reference's SigLIP
+    layer (4 experts, 4304 x 1152) on a 256-CU chip, i.e. a second round that is one third full.  Then every expert's rows are cut
+    into P chunks handled as pseudo-experts of the same persistent kernel (fp32 partials, fixed chunking: deterministic) and the P
+    partials are summed -- split-K for the grouped weight gradient, as `_dense_wgrad` does for one dense expert."""
+    Na, Nb = a.shape[1], b.shape[1]
+    dev = a.device
+    tiles = E * ((Na + 255) // 256) * ((Nb + 255) // 256)
+    P = min(4, (640 + tiles - 1) // tiles, max(1, a.shape[0] // (E * 1024)))      # about 2.5 tiles per CU; targets of 1000 / 1300 measured slower
+    if not _WGRAD_SPLIT or tiles >= 512 or P < 2:
+        out = torch.empty(E, Na, Nb, dtype=pd, device=dev)
+        ops.grouped_wgrad(a, b, bins.offsets, E, out, ops.ptr_table(out, E, Na * Nb * out.element_size()), xcd_order=bins.xcd_order)
+        return out
+    chunk_off = bins.chunk_offsets(P)
+    part = torch.empty(E * P, Na, Nb, dtype=torch.float32, device=dev)
+    ops.grouped_wgrad(a, b, chunk_off, E * P, part, ops.ptr_table(part, E * P, Na * Nb * 4), tag="grouped_wgrad_tn")
+    return part.view(E, P, Na, Nb).sum(1).to(pd)
+
+
 def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool):
     """Returns dx2, dw, (gW1 [E,..], gb1 [E,F]|None, gW2 [E,..], gb2 [E,Dout]|None)."""
     bins, xs, hpre, hact, y = saved
@@ -324,22 +346,12 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
     grads = None
     if need_params:
         pd = tab.param_dtype
-        es = torch.tensor([], dtype=pd).element_size()
-
-        def table(buf):
-            stride = buf[0].numel() * es
-            return ops.ptr_table(buf, E, stride)
-
         if tab.layout == L.B_NK:
-            gW2 = torch.empty(E, tab.Dout, tab.F, dtype=pd, device=dev)
-            ops.grouped_wgrad(dy, hact, bins.offsets, E, gW2, table(gW2), xcd_order=bins.xcd_order)
-            gW1 = torch.empty(E, tab.F, tab.D, dtype=pd, device=dev)
-            ops.grouped_wgrad(dh, xs, bins.offsets, E, gW1, table(gW1), xcd_order=bins.xcd_order)
+            gW2 = _grouped_wgrad(dy, hact, bins, E, pd)          # [E, Dout, F]
+            gW1 = _grouped_wgrad(dh, xs, bins, E, pd)            # [E, F, D]
         else:
-            gW2 = torch.empty(E, tab.F, tab.Dout, dtype=pd, device=dev)
-            ops.grouped_wgrad(hact, dy, bins.offsets, E, gW2, table(gW2), xcd_order=bins.xcd_order)
-            gW1 = torch.empty(E, tab.D, tab.F, dtype=pd, device=dev)
-            ops.grouped_wgrad(xs, dh, bins.offsets, E, gW1, table(gW1), xcd_order=bins.xcd_order)
+            gW2 = _grouped_wgrad(hact, dy, bins, E, pd)          # [E, F, Dout]
+            gW1 = _grouped_wgrad(xs, dh, bins, E, pd)            # [E, D, F]
         gb1 = gb2 = None
         if tab.b2_ptrs is not None:
             gb2 = _grouped_colsum(dy, bins.offsets, E, pd)

@@ -144,12 +144,26 @@ def router_aux_bwd(sm: torch.Tensor, dens: torch.Tensor, lse: Optional[torch.Ten
 # ------------------------------------------------------------------------------------------------ binning
 class Bins:
     """Binned row space of one routing decision."""
-    __slots__ = ("counts", "offsets", "perm", "slot_of", "n", "E", "K", "_xcd_order")
+    __slots__ = ("counts", "offsets", "perm", "slot_of", "n", "E", "K", "_xcd_order", "_chunks")
 
     def __init__(self, counts, offsets, perm, slot_of, n, E, K):
         self.counts, self.offsets, self.perm, self.slot_of = counts, offsets, perm, slot_of
         self.n, self.E, self.K = n, E, K
         self._xcd_order = None
+        self._chunks = {}
+
+    def chunk_offsets(self, P: int) -> torch.Tensor:
+        """offsets [E*P + 1] of every expert's rows cut into P chunks of whole 64-row K-tiles (the last takes the rest): the
+        pseudo-experts of a split-K weight gradient.  Computed once per routing decision."""
+        co = self._chunks.get(P)
+        if co is None:
+            off = self.offsets
+            cnt = (off[1:] - off[:-1]).long()
+            j = cached_arange(P, off.device)
+            starts = off[:-1, None].long() + ((cnt[:, None] * j[None, :]) // P + 63) // 64 * 64
+            starts = torch.minimum(starts, off[1:, None].long())
+            co = self._chunks[P] = torch.cat([starts.reshape(-1), off[-1:].long()]).int()
+        return co
 
     @property
     def xcd_order(self) -> torch.Tensor:

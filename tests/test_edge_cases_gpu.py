@@ -168,3 +168,31 @@ def test_package_imported_before_torch_uses_torchs_hip_runtime():
             "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
+
+
+def test_split_k_grouped_weight_gradient_matches_the_single_pass():
+    """Few experts x few output tiles (the reference's E = 4 LLaVA layers): every expert's rows are cut into chunks handled as
+    pseudo-experts (fp32 partials) and summed.  Against the unsplit launch and an fp64 reference, ragged and empty experts."""
+    from competesmoe_amd import ops, functional as Fn
+    torch.manual_seed(3)
+    E, n, Na, Nb = 4, 9000, 520, 300
+    counts = torch.tensor([4100, 0, 2900, 2000])
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = counts.cumsum(0)
+    bins = ops.Bins(counts.int().cuda(), off.cuda(), None, None, n, E, 1)
+    a = torch.randn(n, Na, device="cuda").bfloat16()
+    b = torch.randn(n, Nb, device="cuda").bfloat16()
+    split = Fn._grouped_wgrad(a, b, bins, E, torch.bfloat16)
+    assert bins._chunks, "the split path was expected for this shape"
+    co = next(iter(bins._chunks.values())).cpu()
+    assert int(co[0]) == 0 and int(co[-1]) == n and bool((co[1:] >= co[:-1]).all())
+    old, Fn._WGRAD_SPLIT = Fn._WGRAD_SPLIT, False
+    try:
+        single = Fn._grouped_wgrad(a, b, bins, E, torch.bfloat16)
+    finally:
+        Fn._WGRAD_SPLIT = old
+    ref = torch.stack([a[int(off[e]):int(off[e + 1])].double().T @ b[int(off[e]):int(off[e + 1])].double() for e in range(E)])
+    scale = float(ref.abs().max())
+    assert float((split.double() - ref).abs().max()) <= 2 ** -7 * scale
+    assert float((single.double() - ref).abs().max()) <= 2 ** -7 * scale
+    assert float(split[1].abs().max()) == 0.0          # the empty expert
