@@ -48,6 +48,7 @@ SIGNATURES = {
     "csmoe_dense_gemm": (_i, [_p, _l, _p, _i, _l, _p, _i, _i, _i, _p, _p, _p, _l, _i, _i, _i, _i, _p]),
     "csmoe_grouped_wgrad": (_i, [_p, _l, _p, _l, _p, _i, _i, _i, _i, _p, _l, _i, _i, _i, _i, _p, _p]),
     "csmoe_expert_order": (_i, [_p, _i, _p, _p]),
+    "csmoe_chunk_offsets": (_i, [_p, _i, _i, _i, _p, _p]),
     "csmoe_dense_wgrad": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _l, _i, _i, _i, _i, _p]),
     "csmoe_grouped_colsum": (_i, [_p, _l, _p, _i, _i, _p, _i, _i, _p]),
     "csmoe_dense_colsum": (_i, [_p, _l, _i, _i, _p, _i, _i, _p]),

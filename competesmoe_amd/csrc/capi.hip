@@ -41,6 +41,7 @@ int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, 
 int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
 int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st);
 int k_expert_order(const int32_t* offsets, int E, int32_t* order, hipStream_t st);
+int k_chunk_offsets(const int32_t* offsets, int E, int P, int align, int32_t* out, hipStream_t st);
 int k_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const float* add, float* out, int T, int K,
                     int D, int mode, hipStream_t st);
 int k_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of, const float* w, void* dy, float* dw, int T, int K,
@@ -308,6 +309,11 @@ int csmoe_gate_bwd_dw(const void* dlogits, const void* x, float* partial, int T,
 int csmoe_expert_order(const int32_t* offsets, int E, int32_t* order, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(E > 0 && E <= 8192 && offsets && order, "expert_order: bad arguments");
   return k_expert_order(offsets, E, order, (hipStream_t)stream);
+}
+
+int csmoe_chunk_offsets(const int32_t* offsets, int E, int P, int align, int32_t* out, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(E > 0 && P > 0 && align > 0 && (int64_t)E * P < (1 << 24) && offsets && out, "chunk_offsets: bad arguments");
+  return k_chunk_offsets(offsets, E, P, align, out, (hipStream_t)stream);
 }
 
 int csmoe_dense_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int Na, int Nb, void* C, int64_t ldc,

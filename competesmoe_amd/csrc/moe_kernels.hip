@@ -1179,6 +1179,19 @@ __global__ void __launch_bounds__(256) combine_bwd_k2_kernel(const TG* dout, con
   }
 }
 
+// Every expert's row range cut into P chunks (the pseudo-experts of a split-K weight gradient / a chunked column sum):
+// out[e * P + j] = min(off[e] + roundup(cnt_e * j / P, align), off[e + 1]),  out[E * P] = off[E].
+__global__ void __launch_bounds__(256) chunk_offsets_kernel(const int32_t* offsets, int E, int P, int align, int32_t* out) {
+  for (int o = blockIdx.x * 256 + threadIdx.x; o <= E * P; o += gridDim.x * 256) {
+    if (o == E * P) { out[o] = offsets[E]; continue; }
+    const int e = o / P, j = o - e * P;
+    const int lo = offsets[e], hi = offsets[e + 1];
+    int64_t st = ((int64_t)(hi - lo) * j) / P;
+    st = (st + align - 1) / align * align;
+    out[o] = (int)min((int64_t)hi, (int64_t)lo + st);
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ host launchers
@@ -1350,8 +1363,11 @@ int k_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int sing
     CSMOE_CHECK_LAUNCH("grouped_colsum");
     return CSMOE_OK;
   }
-  if (dtype == CSMOE_F32)
+  if (dtype == CSMOE_F32 && out_dtype == CSMOE_F32)
     hipLaunchKernelGGL((colsum_kernel<float, float>), grid, block, 0, st, (const float*)G, ldg, offsets, single_M, N, out_ptrs,
+                       single_out);
+  else if (dtype == CSMOE_F32)          // fp32 partial rows summed straight into a bf16 gradient (split-K weight gradients)
+    hipLaunchKernelGGL((colsum_kernel<float, bf16>), grid, block, 0, st, (const float*)G, ldg, offsets, single_M, N, out_ptrs,
                        single_out);
   else if (out_dtype == CSMOE_F32)
     hipLaunchKernelGGL((colsum_kernel<bf16, float>), grid, block, 0, st, (const bf16*)G, ldg, offsets, single_M, N, out_ptrs,
@@ -1507,5 +1523,11 @@ int k_router_aux_bwd(const float* sm, const float* dens, const float* lse, const
   if (dtype == CSMOE_BF16) hipLaunchKernelGGL((router_aux_bwd_kernel<bf16>), grid, block, 0, st, sm, dens, lse, g_bal, g_z, dsm, (bf16*)dlogits, B, N, E);
   else                     hipLaunchKernelGGL((router_aux_bwd_kernel<float>), grid, block, 0, st, sm, dens, lse, g_bal, g_z, dsm, (float*)dlogits, B, N, E);
   CSMOE_CHECK_LAUNCH("router_aux_bwd");
+  return CSMOE_OK;
+}
+
+int k_chunk_offsets(const int32_t* offsets, int E, int P, int align, int32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(chunk_offsets_kernel, dim3(std::min((E * P + 256) / 256, 64)), dim3(256), 0, st, offsets, E, P, align, out);
+  CSMOE_CHECK_LAUNCH("chunk_offsets");
   return CSMOE_OK;
 }

@@ -42,9 +42,8 @@ def _chunked_dense_wgrad(a: torch.Tensor, b: torch.Tensor, out_dtype, P: Optiona
     part = torch.empty(P, Na, Nb, dtype=torch.float32, device=a.device)
     ptrs = ops.ptr_table(part, P, Na * Nb * 4)
     ops.grouped_wgrad(a, b, off, P, part, ptrs, tag="gate_wgrad" if Na <= 64 else "grouped_wgrad_splitk")
-    if Na * Nb >= (1 << 20):      # big partials: the column-sum kernel streams them at HBM rate (torch's sum(0) does not)
-        return ops.dense_colsum(part.view(P, Na * Nb), out_dtype=torch.float32).view(Na, Nb).to(out_dtype)
-    return part.sum(0).to(out_dtype)
+    # sum over the P partials and the cast in one launch of the column-sum kernel (torch: a reduce kernel and a cast)
+    return ops.dense_colsum(part.view(P, Na * Nb), out_dtype=out_dtype).view(Na, Nb)
 
 
 def _dense_wgrad(a: torch.Tensor, b: torch.Tensor, out_dtype) -> torch.Tensor:
@@ -76,7 +75,7 @@ def _chunked_dense_colsum(g: torch.Tensor, out_dtype) -> torch.Tensor:
     part = torch.empty(P, N, dtype=torch.float32, device=g.device)
     ptrs = ops.ptr_table(part, P, N * 4)
     ops.grouped_colsum(g, off, P, part, ptrs)
-    return part.sum(0).to(out_dtype)
+    return ops.dense_colsum(part, out_dtype=out_dtype)
 
 
 def _grouped_colsum(g: torch.Tensor, offsets: torch.Tensor, E: int, pd) -> torch.Tensor:
@@ -92,13 +91,10 @@ def _grouped_colsum(g: torch.Tensor, offsets: torch.Tensor, E: int, pd) -> torch
         ops.grouped_colsum(g, offsets, E, out, ops.ptr_table(out, E, N * es))
         return out
     P = min(64, max(2, 512 // wgs))
-    cnt = (offsets[1:] - offsets[:-1]).long()
-    j = ops.cached_arange(P, dev)
-    starts = offsets[:-1, None].long() + (cnt[:, None] * j[None, :]) // P             # [E, P]; chunk (e, j) ends where (e, j+1) starts
-    chunk_off = torch.cat([starts.reshape(-1), offsets[-1:].long()]).int()
+    chunk_off = ops.chunk_offsets(offsets, E, P)              # chunk (e, j) ends where (e, j+1) starts
     part = torch.empty(E * P, N, dtype=torch.float32, device=dev)
     ops.grouped_colsum(g, chunk_off, E * P, part, ops.ptr_table(part, E * P, N * 4))
-    return part.view(E, P, N).sum(1).to(pd)
+    return ops.sum_partials(part, E, P, pd)
 
 
 class GateLogits(torch.autograd.Function):
@@ -328,7 +324,7 @@ def _grouped_wgrad(a: torch.Tensor, b: torch.Tensor, bins, E: int, pd) -> torch.
     chunk_off = bins.chunk_offsets(P)
     part = torch.empty(E * P, Na, Nb, dtype=torch.float32, device=dev)
     ops.grouped_wgrad(a, b, chunk_off, E * P, part, ops.ptr_table(part, E * P, Na * Nb * 4), tag="grouped_wgrad_tn")
-    return part.view(E, P, Na, Nb).sum(1).to(pd)
+    return ops.sum_partials(part.view(E * P, Na * Nb), E, P, pd).view(E, Na, Nb)
 
 
 def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool):

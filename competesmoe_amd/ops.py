@@ -157,12 +157,7 @@ class Bins:
         pseudo-experts of a split-K weight gradient.  Computed once per routing decision."""
         co = self._chunks.get(P)
         if co is None:
-            off = self.offsets
-            cnt = (off[1:] - off[:-1]).long()
-            j = cached_arange(P, off.device)
-            starts = off[:-1, None].long() + ((cnt[:, None] * j[None, :]) // P + 63) // 64 * 64
-            starts = torch.minimum(starts, off[1:, None].long())
-            co = self._chunks[P] = torch.cat([starts.reshape(-1), off[-1:].long()]).int()
+            co = self._chunks[P] = chunk_offsets(self.offsets, self.E, P, 64)
         return co
 
     @property
@@ -196,6 +191,29 @@ def cached_arange(n: int, device, dtype=torch.int64) -> torch.Tensor:
     if t is None:
         t = _ARANGES[key] = torch.arange(n, device=device, dtype=dtype)
     return t
+
+
+def chunk_offsets(offsets: torch.Tensor, E: int, P: int, align: int = 1) -> torch.Tensor:
+    """[E*P + 1] int32 offsets of every expert's row range cut into P chunks (csmoe_chunk_offsets): one launch."""
+    out = torch.empty(E * P + 1, dtype=torch.int32, device=offsets.device)
+    L.check(lib.csmoe_chunk_offsets(offsets.data_ptr(), E, P, align, out.data_ptr(), _stream()), "chunk_offsets")
+    return out
+
+
+_SEG_OFFSETS = {}
+
+
+def sum_partials(part: torch.Tensor, E: int, P: int, out_dtype) -> torch.Tensor:
+    """part [E*P, N] fp32 partial rows -> [E, N] in out_dtype: sum over the P partials of every expert and the cast in ONE launch of
+    the grouped column-sum kernel (torch: a reduce kernel and a cast)."""
+    N = part.shape[1]
+    key = (E, P, part.device)
+    seg = _SEG_OFFSETS.get(key)
+    if seg is None:
+        seg = _SEG_OFFSETS[key] = (torch.arange(E + 1, dtype=torch.int64) * P).int().to(part.device)
+    out = torch.empty(E, N, dtype=out_dtype, device=part.device)
+    grouped_colsum(part, seg, E, out, ptr_table(out, E, N * out.element_size()))
+    return out
 
 
 def bin_tokens(idx: torch.Tensor, E: int) -> Bins:

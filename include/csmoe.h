@@ -151,6 +151,12 @@ int csmoe_grouped_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, 
  * expert of XCD x or -1.  Computed once per routing decision, passed as `xcd_order` (may be null: contiguous expert ranges). */
 int csmoe_expert_order(const int32_t* offsets, int E, int32_t* order, csmoe_stream_t stream);
 
+/* Row ranges of the E experts cut into P chunks each, out [E * P + 1]: out[e * P + j] = min(offsets[e] + roundup(count_e * j / P,
+ * align), offsets[e + 1]), out[E * P] = offsets[E].  The chunks are handed to csmoe_grouped_wgrad / csmoe_grouped_colsum as
+ * E * P pseudo-experts (split-K with fp32 partials) when E experts alone give too few workgroups for the chip -- the reference's
+ * LLaVA configurations use 4 experts (sft.sh:19-20).  No counterpart upstream. */
+int csmoe_chunk_offsets(const int32_t* offsets, int E, int P, int align, int32_t* out, csmoe_stream_t stream);
+
 /* Dense form: C[Na,Nb] = A[M,Na]^T B[M,Nb]. */
 int csmoe_dense_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int Na, int Nb, void* C, int64_t ldc,
                       int dtype, int out_dtype, int accumulate, int force_generic, csmoe_stream_t stream);

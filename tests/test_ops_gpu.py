@@ -548,3 +548,32 @@ def test_k2_fast_kernels_are_bit_identical_to_the_generic_ones(tmp_path):
     assert set(fast) == set(gen)
     for k in fast:
         assert torch.equal(fast[k], gen[k]), k
+
+
+@pytest.mark.parametrize("E,P,N", [(1, 2, 8), (4, 2, 1000), (3, 5, 4099), (4, 2, 4304 * 64)])
+def test_sum_partials_and_chunk_offsets(E, P, N):
+    """fp32 partial rows -> per-expert sums in bf16 / fp32 in one launch (fp32-in, bf16-out column sums), and the chunk offsets of
+    csmoe_chunk_offsets against their definition."""
+    part = torch.randn(E * P, N, device=DEV)
+    for od in (torch.bfloat16, torch.float32):
+        out = ops.sum_partials(part, E, P, od)
+        ref = part.view(E, P, N).double().sum(1)
+        assert out.dtype == od and out.shape == (E, N)
+        assert float((out.double() - ref).abs().max()) <= (2 ** -8 if od == torch.bfloat16 else 1e-6) * float(ref.abs().max())
+    d = ops.dense_colsum(part, out_dtype=torch.bfloat16)
+    assert d.dtype == torch.bfloat16 and float((d.double() - part.double().sum(0)).abs().max()) <= 2 ** -8 * float(part.double().sum(0).abs().max())
+    counts = torch.randint(0, 5000, (E,))
+    counts[0] = 0
+    off = torch.zeros(E + 1, dtype=torch.int32)
+    off[1:] = counts.cumsum(0)
+    for align in (1, 64):
+        co = ops.chunk_offsets(off.to(DEV), E, P, align).cpu().long()
+        want = []
+        for e in range(E):
+            lo, hi = int(off[e]), int(off[e + 1])
+            for j in range(P):
+                st = ((hi - lo) * j) // P
+                st = (st + align - 1) // align * align
+                want.append(min(hi, lo + st))
+        want.append(int(off[E]))
+        assert co.tolist() == want
