@@ -465,17 +465,16 @@ class MoEFFNPacked(torch.autograd.Function):
         if _WEIGHT_CACHE_ON and not v_hit and values.dtype != op:
             _remember(values, op, v_op)
         es = k_op.element_size()
-        ar = ops.cached_arange(E, dev)
         b_op = None
         b1 = None
         if bias is not None:
             b_op = bias.contiguous() if bias.dtype == op else bias.to(op)
-            b1 = b_op.data_ptr() + ar * (F * es)
+            b1 = ops.ptr_table(b_op, E, F * es)
         ob = None
         if o_bias is not None:
             ob = o_bias.contiguous() if o_bias.dtype == op else o_bias.to(op)
         tab = ExpertTable(E=E, D=D, F=F, Dout=Dout, layout=L.B_KN, act=act,
-                          w1_ptrs=k_op.data_ptr() + ar * (D * F * es), w2_ptrs=v_op.data_ptr() + ar * (F * Dout * es),
+                          w1_ptrs=ops.ptr_table(k_op, E, D * F * es), w2_ptrs=ops.ptr_table(v_op, E, F * Dout * es),
                           b1_ptrs=b1, b2_ptrs=None, param_dtype=keys.dtype)
         out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, ob, residual=None if residual is None else residual.contiguous(),
                                   before_gemm2=side)

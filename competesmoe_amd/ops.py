@@ -169,17 +169,26 @@ class Bins:
 
 
 _STRIDE_TABLES = {}
+_PTR_TABLES = {}     # (base address, n, stride) -> device table; content is a pure function of the key
 
 
 def ptr_table(buf: torch.Tensor, n: int, stride_bytes: int) -> torch.Tensor:
     """Device table of n pointers buf.data_ptr() + i * stride_bytes.  The i * stride part is cached per (n, stride, device), so a
     table costs ONE tiny add kernel per call instead of arange + mul + add (the backward builds four of them per step, and at the
     reference's small LLaVA shapes a step is bound by the number of launches)."""
+    base = buf.data_ptr()
+    full = (base, n, stride_bytes, buf.device)
+    tab = _PTR_TABLES.get(full)       # the caching allocator hands the same addresses out step after step: usually a hit, no launch
+    if tab is not None:
+        return tab
     key = (n, stride_bytes, buf.device)
     offs = _STRIDE_TABLES.get(key)
     if offs is None:
         offs = _STRIDE_TABLES[key] = torch.arange(n, device=buf.device, dtype=torch.int64) * stride_bytes
-    return offs + buf.data_ptr()
+    if len(_PTR_TABLES) >= 512:
+        _PTR_TABLES.clear()
+    tab = _PTR_TABLES[full] = offs + base
+    return tab
 
 
 _ARANGES = {}
