@@ -683,6 +683,46 @@ __global__ void __launch_bounds__(256) colsum_bf16x8_kernel(const bf16* G, int64
   }
 }
 
+// fp32 rows, very wide and few (the fp32 partials of a split-K weight gradient: 2-4 rows of millions of columns): a thread owns 8
+// consecutive columns (two 16-byte loads per row), four rows in flight, one 16 / 32-byte store.  Used when the column blocks alone
+// fill the chip.
+template <typename TOut>
+__global__ void __launch_bounds__(256) colsum_f32_wide_kernel(const float* G, int64_t ldg, const int32_t* offsets, int single_M, int N,
+                                                              void* const* out_ptrs, void* single_out) {
+  const int e = blockIdx.y;
+  const int r0 = offsets ? offsets[e] : 0, r1 = offsets ? offsets[e + 1] : single_M;
+  const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c0 >= N) return;
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* p = G + (int64_t)(r + u) * ldg + c0;
+      a[u] = *(const f32x4*)p;
+      b[u] = *(const f32x4*)(p + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sa += a[u]; sb += b[u]; }
+  }
+  for (; r < r1; ++r) {
+    const float* p = G + (int64_t)r * ldg + c0;
+    sa += *(const f32x4*)p;
+    sb += *(const f32x4*)(p + 4);
+  }
+  TOut* o = (TOut*)(out_ptrs ? out_ptrs[e] : single_out) + c0;
+  if constexpr (std::is_same<TOut, float>::value) {
+    *(f32x4*)o = sa;
+    *(f32x4*)(o + 4) = sb;
+  } else {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = (bf16)sa[j]; v[4 + j] = (bf16)sb[j]; }
+    *(bf16x8*)o = v;
+  }
+}
+
 // =====================================================================================================================
 // Competition affinity: aff[r] = mean_d softplus(y[r,d])  (competesmoe.py:242) and its backward
 // =====================================================================================================================
@@ -1360,6 +1400,17 @@ int k_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int sing
       hipLaunchKernelGGL((colsum_bf16x8_kernel<float>), g8, block, 0, st, (const bf16*)G, ldg, offsets, single_M, N, out_ptrs, single_out);
     else
       hipLaunchKernelGGL((colsum_bf16x8_kernel<bf16>), g8, block, 0, st, (const bf16*)G, ldg, offsets, single_M, N, out_ptrs, single_out);
+    CSMOE_CHECK_LAUNCH("grouped_colsum");
+    return CSMOE_OK;
+  }
+  if (dtype == CSMOE_F32 && N % 8 == 0 && ldg % 8 == 0 && (((uintptr_t)G | (uintptr_t)single_out) & 15) == 0 &&
+      (int64_t)((N / 8 + 255) / 256) * E >= 256) {
+    // output alignment: rows of the out tensors start at multiples of N elements from 16-byte aligned bases (torch allocations)
+    dim3 gw((N / 8 + 255) / 256, E);
+    if (out_dtype == CSMOE_F32)
+      hipLaunchKernelGGL((colsum_f32_wide_kernel<float>), gw, block, 0, st, (const float*)G, ldg, offsets, single_M, N, out_ptrs, single_out);
+    else
+      hipLaunchKernelGGL((colsum_f32_wide_kernel<bf16>), gw, block, 0, st, (const float*)G, ldg, offsets, single_M, N, out_ptrs, single_out);
     CSMOE_CHECK_LAUNCH("grouped_colsum");
     return CSMOE_OK;
   }
