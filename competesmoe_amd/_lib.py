@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("CSMOE_LIB") or os.path.join(_HERE, "lib", "libcsmoe_h
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_TANH, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4, 5
-SEL_SOFTMAX, SEL_RAW, SEL_TOPK_SOFTMAX, SEL_SIGMOID = 0, 1, 2, 3
+SEL_SOFTMAX, SEL_RAW, SEL_TOPK_SOFTMAX, SEL_SIGMOID, SEL_TOPK_SIGMOID = 0, 1, 2, 3, 4
 COMBINE_SEQ, COMBINE_DOT, COMBINE_SEQ_RW = 0, 1, 2
 B_NK, B_KN = 0, 1
 EPI_PLAIN, EPI_BIAS, EPI_BIAS_ACT, EPI_ACTGRAD = 0, 1, 2, 3
@@ -35,8 +35,8 @@ SIGNATURES = {
     "csmoe_last_error": (C.c_char_p, []),
     "csmoe_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "csmoe_gate_logits": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
-    "csmoe_router_select": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
-    "csmoe_router_select_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "csmoe_router_select": (_i, [_p, _i, _i, _i, _i, _i, _i, C.c_float, _p, _p, _p, _p]),
+    "csmoe_router_select_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, C.c_float, _p, _p, _p, _p, _p, _p, _p]),
     "csmoe_bin_workspace_bytes": (_l, [_i, _i]),
     "csmoe_bin_tokens": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),
     "csmoe_dispatch_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
@@ -52,8 +52,8 @@ SIGNATURES = {
     "csmoe_dense_wgrad": (_i, [_p, _l, _p, _l, _i, _i, _i, _p, _l, _i, _i, _i, _i, _p]),
     "csmoe_grouped_colsum": (_i, [_p, _l, _p, _i, _i, _p, _i, _i, _p]),
     "csmoe_dense_colsum": (_i, [_p, _l, _i, _i, _p, _i, _i, _p]),
-    "csmoe_softplus_mean": (_i, [_p, _p, _i, _i, _i, _p]),
-    "csmoe_softplus_mean_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "csmoe_softplus_mean": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "csmoe_softplus_mean_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "csmoe_router_aux_workspace_floats": (_l, [_i, _i, _i]),
     "csmoe_router_aux": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "csmoe_router_aux_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

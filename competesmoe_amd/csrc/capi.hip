@@ -27,8 +27,8 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
                  hipStream_t st);
 int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
               void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st, const int32_t* xcd_order = nullptr);
-int k_router_select(const void*, int, int, int, int, int, int, float*, int32_t*, float*, hipStream_t);
-int k_router_select_bwd(const void*, int, int, int, int, int, int, const float*, const int32_t*, const float*, const float*,
+int k_router_select(const void*, int, int, int, int, int, int, float, float*, int32_t*, float*, hipStream_t);
+int k_router_select_bwd(const void*, int, int, int, int, int, int, float, const float*, const int32_t*, const float*, const float*,
                         const float*, void*, hipStream_t);
 int64_t k_bin_workspace_bytes(int n, int E);
 int k_bin_tokens(const int32_t*, int, int, int32_t*, int32_t*, int32_t*, int32_t*, void*, hipStream_t);
@@ -38,7 +38,7 @@ int k_combine(const void*, const int32_t*, const int32_t*, const float*, const v
               hipStream_t);
 int k_combine_bwd(const void*, const void*, const int32_t*, const float*, void*, float*, int, int, int, int, hipStream_t);
 int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, void*, int, int, hipStream_t);
-int k_softplus_mean(const void*, void*, int, int, int, hipStream_t);
+int k_softplus_mean(const void*, void*, int, int, int, int, int, hipStream_t);
 int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st);
 int k_expert_order(const int32_t* offsets, int E, int32_t* order, hipStream_t st);
 int k_chunk_offsets(const int32_t* offsets, int E, int P, int align, int32_t* out, hipStream_t st);
@@ -67,7 +67,7 @@ int k_layernorm_fwd(const void* x, const void* gamma, const void* beta, float ep
 int k_layernorm_bwd_blocks(int T);
 int k_layernorm_bwd(const void* dxn, const void* dxn2, const void* x, const void* gamma, const float* mean, const float* rstd,
                     const void* add, void* dx, float* partial, int T, int D, int dtype, hipStream_t st);
-int k_softplus_mean_bwd(const void*, const void*, const void*, void*, int, int, int, hipStream_t);
+int k_softplus_mean_bwd(const void*, const void*, const void*, void*, int, int, int, int, int, hipStream_t);
 
 static thread_local char g_err[512] = "";
 
@@ -137,27 +137,29 @@ int csmoe_gate_logits(const void* x, const void* w_gate, void* logits, int T, in
                              CSMOE_EPI_PLAIN, CSMOE_ACT_NONE, dtype, w_gate, nullptr, st);
 }
 
-int csmoe_router_select(const void* scores, int dtype, int T, int E, int K, int sel_mode, int round_sum_bf16, float* softmax,
-                        int32_t* idx, float* w, csmoe_stream_t stream) {
+int csmoe_router_select(const void* scores, int dtype, int T, int E, int K, int sel_mode, int round_sum_bf16, float sel_param,
+                        float* softmax, int32_t* idx, float* w, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype), "router_select: bad dtype %d", dtype);
   CSMOE_CHECK_ARG(T >= 0 && E > 0 && E <= 1024, "router_select: E=%d out of range (1..1024)", E);
   CSMOE_CHECK_ARG(K > 0 && K <= E && K <= 64, "router_select: K=%d out of range (1..min(E,64))", K);
-  CSMOE_CHECK_ARG(sel_mode >= 0 && sel_mode <= 3, "router_select: bad mode %d", sel_mode);
+  CSMOE_CHECK_ARG(sel_mode >= 0 && sel_mode <= 4, "router_select: bad mode %d", sel_mode);
+  CSMOE_CHECK_ARG(sel_mode != CSMOE_SEL_TOPK_SIGMOID || sel_param != 0.f, "router_select: SEL_TOPK_SIGMOID needs a non-zero scale");
   if (T == 0) return CSMOE_OK;
   CSMOE_CHECK_ARG(scores && idx && w, "router_select: null pointer");
-  return k_router_select(scores, dtype, T, E, K, sel_mode, round_sum_bf16, softmax, idx, w, (hipStream_t)stream);
+  return k_router_select(scores, dtype, T, E, K, sel_mode, round_sum_bf16, sel_param, softmax, idx, w, (hipStream_t)stream);
 }
 
 int csmoe_router_select_bwd(const void* scores, int dtype, int T, int E, int K, int sel_mode, int round_sum_bf16,
-                            const float* softmax, const int32_t* idx, const float* w, const float* dw, const float* dsoftmax,
+                            float sel_param, const float* softmax, const int32_t* idx, const float* w, const float* dw, const float* dsoftmax,
                             void* dscores, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype), "router_select_bwd: bad dtype %d", dtype);
   CSMOE_CHECK_ARG(T >= 0 && E > 0 && E <= 1024 && K > 0 && K <= E && K <= 64, "router_select_bwd: bad shape");
-  CSMOE_CHECK_ARG(sel_mode >= 0 && sel_mode <= 3, "router_select_bwd: bad mode %d", sel_mode);
+  CSMOE_CHECK_ARG(sel_mode >= 0 && sel_mode <= 4, "router_select_bwd: bad mode %d", sel_mode);
+  CSMOE_CHECK_ARG(sel_mode != CSMOE_SEL_TOPK_SIGMOID || sel_param != 0.f, "router_select_bwd: SEL_TOPK_SIGMOID needs a non-zero scale");
   if (T == 0) return CSMOE_OK;
   CSMOE_CHECK_ARG(scores && idx && w && dscores, "router_select_bwd: null pointer");
   CSMOE_CHECK_ARG(softmax || (sel_mode != CSMOE_SEL_SOFTMAX && !dsoftmax), "router_select_bwd: softmax required");
-  return k_router_select_bwd(scores, dtype, T, E, K, sel_mode, round_sum_bf16, softmax, idx, w, dw, dsoftmax, dscores,
+  return k_router_select_bwd(scores, dtype, T, E, K, sel_mode, round_sum_bf16, sel_param, softmax, idx, w, dw, dsoftmax, dscores,
                              (hipStream_t)stream);
 }
 
@@ -344,17 +346,19 @@ int csmoe_dense_colsum(const void* G, int64_t ldg, int M, int N, void* out, int 
   return k_colsum(G, ldg, nullptr, 1, M, N, nullptr, out, dtype, out_dtype, (hipStream_t)stream);
 }
 
-int csmoe_softplus_mean(const void* y, void* aff, int R, int D, int dtype, csmoe_stream_t stream) {
+int csmoe_softplus_mean(const void* y, void* aff, int R, int D, int dtype, int aff_dtype, int precise, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && R >= 0 && D > 0, "softplus_mean: bad arguments");
+  CSMOE_CHECK_ARG(aff_dtype == dtype || aff_dtype == CSMOE_F32, "softplus_mean: affinities are in the rows' dtype or fp32");
   CSMOE_CHECK_ARG(R == 0 || (y && aff), "softplus_mean: null pointer");
-  return k_softplus_mean(y, aff, R, D, dtype, (hipStream_t)stream);
+  return k_softplus_mean(y, aff, R, D, dtype, aff_dtype, precise, (hipStream_t)stream);
 }
 
-int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype,
+int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype, int aff_dtype, int precise,
                             csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && R >= 0 && D > 0, "softplus_mean_bwd: bad arguments");
+  CSMOE_CHECK_ARG(aff_dtype == dtype || aff_dtype == CSMOE_F32, "softplus_mean_bwd: affinities are in the rows' dtype or fp32");
   CSMOE_CHECK_ARG(R == 0 || (y && daff && dy), "softplus_mean_bwd: null pointer");
-  return k_softplus_mean_bwd(y, daff, dy_add, dy, R, D, dtype, (hipStream_t)stream);
+  return k_softplus_mean_bwd(y, daff, dy_add, dy, R, D, dtype, aff_dtype, precise, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -34,7 +34,8 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 
 template <int VPL>
 __global__ void __launch_bounds__(256) router_select_kernel(const void* scores, int dtype, int T, int E, int K, int mode,
-                                                            int round_sum_bf16, float* softmax, int32_t* idx, float* w) {
+                                                            int round_sum_bf16, float sel_param, float* softmax, int32_t* idx,
+                                                            float* w) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -95,7 +96,14 @@ __global__ void __launch_bounds__(256) router_select_kernel(const void* scores, 
     return;
   }
   float denom, wk;
-  if (mode == CSMOE_SEL_SOFTMAX) {
+  if (mode == CSMOE_SEL_TOPK_SIGMOID) {
+    // w_k = sigmoid(logit_k / scale) in the logits' dtype, renormalised by the fp32 K-sum rounded to x.dtype (quotient fp32)
+    const float sv = lane < K ? round_dt(sigmoidf_(round_dt(myv / sel_param, dtype)), dtype) : 0.f;
+    float ssum = 0.f;
+    for (int k = 0; k < K; ++k) ssum += __shfl(sv, k, 64);
+    denom = round_sum_bf16 ? (float)(bf16)ssum : ssum;
+    wk = sv / denom;
+  } else if (mode == CSMOE_SEL_SOFTMAX) {
     denom = round_sum_bf16 ? (float)(bf16)vsum : vsum;
     wk = myv / denom;
   } else if (mode == CSMOE_SEL_RAW) {
@@ -110,7 +118,8 @@ __global__ void __launch_bounds__(256) router_select_kernel(const void* scores, 
 
 template <int VPL>
 __global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scores, int dtype, int T, int E, int K, int mode,
-                                                                int round_sum_bf16, const float* softmax, const int32_t* idx,
+                                                                int round_sum_bf16, float sel_param, const float* softmax,
+                                                                const int32_t* idx,
                                                                 const float* w, const float* dw, const float* dsoftmax,
                                                                 void* dscores) {
   const int lane = threadIdx.x & 63;
@@ -126,6 +135,8 @@ __global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scor
     myw = w[(int64_t)t * K + lane];
     if (mode == CSMOE_SEL_SOFTMAX) myv = softmax[base + myi];
     else if (mode == CSMOE_SEL_SIGMOID) myv = round_dt(sigmoidf_(load_score(scores, base + myi, dtype)), dtype);
+    else if (mode == CSMOE_SEL_TOPK_SIGMOID)
+      myv = round_dt(sigmoidf_(round_dt(load_score(scores, base + myi, dtype) / sel_param, dtype)), dtype);
     else myv = load_score(scores, base + myi, dtype);
   }
   float dv = 0.f;   // gradient w.r.t. the selected value of slot `lane`
@@ -135,12 +146,13 @@ __global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scor
   } else {
     float ssum = wave_sum(myv);
     float denom;
-    if (mode == CSMOE_SEL_SOFTMAX) denom = round_sum_bf16 ? (float)(bf16)ssum : ssum;
+    if (mode == CSMOE_SEL_SOFTMAX || mode == CSMOE_SEL_TOPK_SIGMOID) denom = round_sum_bf16 ? (float)(bf16)ssum : ssum;
     else if (mode == CSMOE_SEL_RAW) denom = round_dt(ssum, dtype);
     else denom = round_dt(ssum, dtype) + 1e-20f;
     float dot = wave_sum(mydw * myv);
     dv = mydw / denom - dot / (denom * denom);
     if (mode == CSMOE_SEL_SIGMOID) dv *= myv * (1.f - myv);
+    if (mode == CSMOE_SEL_TOPK_SIGMOID) dv *= myv * (1.f - myv) / sel_param;
   }
   // scatter dv to the expert positions; softmax-path gradient
   float g[VPL], p[VPL];
@@ -726,19 +738,31 @@ __global__ void __launch_bounds__(256) colsum_f32_wide_kernel(const float* G, in
 // =====================================================================================================================
 // Competition affinity: aff[r] = mean_d softplus(y[r,d])  (competesmoe.py:242) and its backward
 // =====================================================================================================================
-// softplus with torch's threshold (x > 20 -> x); fast exp / log: the value is rounded to x.dtype and averaged over D right after
-__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : __logf(1.f + __expf(x)); }
-__device__ __forceinline__ float sp_sigmoidf_(float x) { return x > 20.f ? 1.f : __frcp_rn(1.f + __expf(-x)); }
+// softplus with torch's threshold (x > 20 -> x).  PRECISE: expf / log1pf as torch computes it; otherwise the hardware exp / log
+// (the value is averaged over D right after).
+template <bool PRECISE>
+__device__ __forceinline__ float softplusf_(float x) {
+  if constexpr (PRECISE) return x > 20.f ? x : log1pf(expf(x));
+  else return x > 20.f ? x : __logf(1.f + __expf(x));
+}
+template <bool PRECISE>
+__device__ __forceinline__ float sp_sigmoidf_(float x) {
+  if constexpr (PRECISE) return 1.f / (1.f + expf(-x));
+  else return x > 20.f ? 1.f : __frcp_rn(1.f + __expf(-x));
+}
 
 template <typename T> struct Vec16;
 template <> struct Vec16<bf16> { static constexpr int N = 8; typedef bf16x8 V; };
 template <> struct Vec16<float> { static constexpr int N = 4; typedef f32x4 V; };
 
-// wave per row, 16-byte accesses when VEC (D % N == 0, 16-byte aligned rows)
-template <typename T, bool VEC>
-__global__ void __launch_bounds__(256) softplus_mean_kernel(const T* y, T* aff, int R, int D) {
+// wave per row, 16-byte accesses when VEC (D % N == 0, 16-byte aligned rows).  TA = dtype of the affinities: T (the LLaVA stack:
+// softplus and mean are x.dtype tensor ops, every softplus value is rounded to T before the mean) or float around bf16 rows (the
+// pretrain stack under CUDA autocast: F.softplus is an fp32-policy op, so softplus, mean and everything after are fp32).
+template <typename T, typename TA, bool VEC, bool PRECISE>
+__global__ void __launch_bounds__(256) softplus_mean_kernel(const T* y, TA* aff, int R, int D) {
   typedef typename Vec16<T>::V V;
   constexpr int N = Vec16<T>::N;
+  constexpr bool RND = std::is_same<T, TA>::value;
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
@@ -748,26 +772,35 @@ __global__ void __launch_bounds__(256) softplus_mean_kernel(const T* y, T* aff, 
       for (int d = lane * N; d < D; d += 64 * N) {
         const V v = *(const V*)(y + (int64_t)r * D + d);
 #pragma unroll
-        for (int j = 0; j < N; ++j) s += DT<T>::rnd(softplusf_((float)v[j]));
+        for (int j = 0; j < N; ++j) {
+          const float sp = softplusf_<PRECISE>((float)v[j]);
+          s += RND ? DT<T>::rnd(sp) : sp;
+        }
       }
     } else {
-      for (int d = lane; d < D; d += 64) s += DT<T>::rnd(softplusf_(DT<T>::ld(y + (int64_t)r * D + d)));
+      for (int d = lane; d < D; d += 64) {
+        const float sp = softplusf_<PRECISE>(DT<T>::ld(y + (int64_t)r * D + d));
+        s += RND ? DT<T>::rnd(sp) : sp;
+      }
     }
     s = wave_sum(s);
-    if (lane == 0) DT<T>::st(aff + r, s / (float)D);
+    if (lane == 0) DT<TA>::st(aff + r, s / (float)D);
   }
 }
 
-// dy[r,d] = round(round(daff[r] / D) * sigmoid(y[r,d])) (+ dy_add[r,d])
-template <typename T, bool VEC>
-__global__ void __launch_bounds__(256) softplus_mean_bwd_kernel(const T* y, const T* daff, const T* dy_add, T* dy, int R, int D) {
+// TA == T:     dy[r,d] = round(round(daff[r] / D) * sigmoid(y[r,d])) (+ dy_add[r,d])
+// TA == float: dy[r,d] = round(daff[r] / D * sigmoid(y[r,d]))        (+ dy_add[r,d])   (fp32 chain, one cast: autograd of .float())
+template <typename T, typename TA, bool VEC, bool PRECISE>
+__global__ void __launch_bounds__(256) softplus_mean_bwd_kernel(const T* y, const TA* daff, const T* dy_add, T* dy, int R, int D) {
   typedef typename Vec16<T>::V V;
   constexpr int N = Vec16<T>::N;
+  constexpr bool RND = std::is_same<T, TA>::value;
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
   for (int r = wave_g; r < R; r += nw) {
-    const float g = DT<T>::rnd(DT<T>::ld(daff + r) / (float)D);
+    const float g0 = DT<TA>::ld(daff + r) / (float)D;
+    const float g = RND ? DT<T>::rnd(g0) : g0;
     if constexpr (VEC) {
       for (int d = lane * N; d < D; d += 64 * N) {
         const int64_t o = (int64_t)r * D + d;
@@ -777,7 +810,7 @@ __global__ void __launch_bounds__(256) softplus_mean_bwd_kernel(const T* y, cons
         V out;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-          float t = DT<T>::rnd(g * sp_sigmoidf_((float)v[j]));
+          float t = DT<T>::rnd(g * sp_sigmoidf_<PRECISE>((float)v[j]));
           if (dy_add) t = DT<T>::rnd(t + (float)a[j]);
           out[j] = (T)t;
         }
@@ -786,7 +819,7 @@ __global__ void __launch_bounds__(256) softplus_mean_bwd_kernel(const T* y, cons
     } else {
       for (int d = lane; d < D; d += 64) {
         const int64_t o = (int64_t)r * D + d;
-        float v = DT<T>::rnd(g * sp_sigmoidf_(DT<T>::ld(y + o)));
+        float v = DT<T>::rnd(g * sp_sigmoidf_<PRECISE>(DT<T>::ld(y + o)));
         if (dy_add) v = DT<T>::rnd(v + DT<T>::ld(dy_add + o));
         DT<T>::st(dy + o, v);
       }
@@ -1246,19 +1279,20 @@ __global__ void __launch_bounds__(256) chunk_offsets_kernel(const int32_t* offse
     else hipLaunchKernelGGL((KERNEL<16>), grid, block, 0, st, __VA_ARGS__);                       \
   } while (0)
 
-int k_router_select(const void* scores, int dtype, int T, int E, int K, int mode, int round_sum_bf16, float* softmax,
-                    int32_t* idx, float* w, hipStream_t st) {
+int k_router_select(const void* scores, int dtype, int T, int E, int K, int mode, int round_sum_bf16, float sel_param,
+                    float* softmax, int32_t* idx, float* w, hipStream_t st) {
   if (T == 0) return CSMOE_OK;
-  SEL_DISPATCH(router_select_kernel, scores, dtype, T, E, K, mode, round_sum_bf16, softmax, idx, w);
+  SEL_DISPATCH(router_select_kernel, scores, dtype, T, E, K, mode, round_sum_bf16, sel_param, softmax, idx, w);
   CSMOE_CHECK_LAUNCH("router_select");
   return CSMOE_OK;
 }
 
-int k_router_select_bwd(const void* scores, int dtype, int T, int E, int K, int mode, int round_sum_bf16, const float* softmax,
-                        const int32_t* idx, const float* w, const float* dw, const float* dsoftmax, void* dscores,
-                        hipStream_t st) {
+int k_router_select_bwd(const void* scores, int dtype, int T, int E, int K, int mode, int round_sum_bf16, float sel_param,
+                        const float* softmax, const int32_t* idx, const float* w, const float* dw, const float* dsoftmax,
+                        void* dscores, hipStream_t st) {
   if (T == 0) return CSMOE_OK;
-  SEL_DISPATCH(router_select_bwd_kernel, scores, dtype, T, E, K, mode, round_sum_bf16, softmax, idx, w, dw, dsoftmax, dscores);
+  SEL_DISPATCH(router_select_bwd_kernel, scores, dtype, T, E, K, mode, round_sum_bf16, sel_param, softmax, idx, w, dw, dsoftmax,
+               dscores);
   CSMOE_CHECK_LAUNCH("router_select_bwd");
   return CSMOE_OK;
 }
@@ -1430,35 +1464,53 @@ int k_colsum(const void* G, int64_t ldg, const int32_t* offsets, int E, int sing
   return CSMOE_OK;
 }
 
-int k_softplus_mean(const void* y, void* aff, int R, int D, int dtype, hipStream_t st) {
+template <typename T, typename TA>
+static void softplus_launch(const void* y, void* aff, int R, int D, bool vec, int precise, dim3 grid, dim3 block, hipStream_t st) {
+  if (vec) {
+    if (precise) hipLaunchKernelGGL((softplus_mean_kernel<T, TA, true, true>), grid, block, 0, st, (const T*)y, (TA*)aff, R, D);
+    else         hipLaunchKernelGGL((softplus_mean_kernel<T, TA, true, false>), grid, block, 0, st, (const T*)y, (TA*)aff, R, D);
+  } else {
+    if (precise) hipLaunchKernelGGL((softplus_mean_kernel<T, TA, false, true>), grid, block, 0, st, (const T*)y, (TA*)aff, R, D);
+    else         hipLaunchKernelGGL((softplus_mean_kernel<T, TA, false, false>), grid, block, 0, st, (const T*)y, (TA*)aff, R, D);
+  }
+}
+
+int k_softplus_mean(const void* y, void* aff, int R, int D, int dtype, int aff_dtype, int precise, hipStream_t st) {
   if (R == 0) return CSMOE_OK;
   dim3 grid(stride_grid(R)), block(256);
   const bool al = ((uintptr_t)y & 15) == 0;
   if (dtype == CSMOE_BF16) {
-    if (D % 8 == 0 && al) hipLaunchKernelGGL((softplus_mean_kernel<bf16, true>), grid, block, 0, st, (const bf16*)y, (bf16*)aff, R, D);
-    else                  hipLaunchKernelGGL((softplus_mean_kernel<bf16, false>), grid, block, 0, st, (const bf16*)y, (bf16*)aff, R, D);
+    const bool vec = D % 8 == 0 && al;
+    if (aff_dtype == CSMOE_BF16) softplus_launch<bf16, bf16>(y, aff, R, D, vec, precise, grid, block, st);
+    else                         softplus_launch<bf16, float>(y, aff, R, D, vec, precise, grid, block, st);
   } else {
-    if (D % 4 == 0 && al) hipLaunchKernelGGL((softplus_mean_kernel<float, true>), grid, block, 0, st, (const float*)y, (float*)aff, R, D);
-    else                  hipLaunchKernelGGL((softplus_mean_kernel<float, false>), grid, block, 0, st, (const float*)y, (float*)aff, R, D);
+    softplus_launch<float, float>(y, aff, R, D, D % 4 == 0 && al, precise, grid, block, st);
   }
   CSMOE_CHECK_LAUNCH("softplus_mean");
   return CSMOE_OK;
 }
 
-int k_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype, hipStream_t st) {
+template <typename T, typename TA>
+static void softplus_bwd_launch(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, bool vec, int precise,
+                                dim3 grid, dim3 block, hipStream_t st) {
+#define SPB(V, P) hipLaunchKernelGGL((softplus_mean_bwd_kernel<T, TA, V, P>), grid, block, 0, st, (const T*)y, (const TA*)daff, \
+                                     (const T*)dy_add, (T*)dy, R, D)
+  if (vec) { if (precise) SPB(true, true); else SPB(true, false); }
+  else     { if (precise) SPB(false, true); else SPB(false, false); }
+#undef SPB
+}
+
+int k_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype, int aff_dtype,
+                        int precise, hipStream_t st) {
   if (R == 0) return CSMOE_OK;
   dim3 grid(stride_grid(R)), block(256);
-  const bool al = (((uintptr_t)y | (uintptr_t)dy_add | (uintptr_t)dy) & 15) == 0;
+  const bool al = (((uintptr_t)y | (uintptr_t)dy | (uintptr_t)dy_add) & 15) == 0;
   if (dtype == CSMOE_BF16) {
-    if (D % 8 == 0 && al)
-      hipLaunchKernelGGL((softplus_mean_bwd_kernel<bf16, true>), grid, block, 0, st, (const bf16*)y, (const bf16*)daff, (const bf16*)dy_add, (bf16*)dy, R, D);
-    else
-      hipLaunchKernelGGL((softplus_mean_bwd_kernel<bf16, false>), grid, block, 0, st, (const bf16*)y, (const bf16*)daff, (const bf16*)dy_add, (bf16*)dy, R, D);
+    const bool vec = D % 8 == 0 && al;
+    if (aff_dtype == CSMOE_BF16) softplus_bwd_launch<bf16, bf16>(y, daff, dy_add, dy, R, D, vec, precise, grid, block, st);
+    else                         softplus_bwd_launch<bf16, float>(y, daff, dy_add, dy, R, D, vec, precise, grid, block, st);
   } else {
-    if (D % 4 == 0 && al)
-      hipLaunchKernelGGL((softplus_mean_bwd_kernel<float, true>), grid, block, 0, st, (const float*)y, (const float*)daff, (const float*)dy_add, (float*)dy, R, D);
-    else
-      hipLaunchKernelGGL((softplus_mean_bwd_kernel<float, false>), grid, block, 0, st, (const float*)y, (const float*)daff, (const float*)dy_add, (float*)dy, R, D);
+    softplus_bwd_launch<float, float>(y, daff, dy_add, dy, R, D, D % 4 == 0 && al, precise, grid, block, st);
   }
   CSMOE_CHECK_LAUNCH("softplus_mean_bwd");
   return CSMOE_OK;

@@ -182,22 +182,23 @@ class RouterSelect(torch.autograd.Function):
     variants (deepseekv2.py:140-142, deepseekv3.py:147-151)."""
 
     @staticmethod
-    def forward(ctx, scores: torch.Tensor, K: int, mode: int, round_sum_bf16: bool):
+    def forward(ctx, scores: torch.Tensor, K: int, mode: int, round_sum_bf16: bool, param: float = 1.0):
+        """`param`: the scale of SEL_TOPK_SIGMOID (`args.scale_weight`, pretrain competesmoe.py:476-483)."""
         scores = scores.contiguous()
-        sm, idx, w = ops.router_select(scores, K, mode, round_sum_bf16, want_softmax=True)
+        sm, idx, w = ops.router_select(scores, K, mode, round_sum_bf16, want_softmax=True, param=param)
         ctx.save_for_backward(scores, sm, idx, w)
-        ctx.cfg = (K, mode, round_sum_bf16)
+        ctx.cfg = (K, mode, round_sum_bf16, param)
         ctx.mark_non_differentiable(idx)
         return sm, idx, w
 
     @staticmethod
     def backward(ctx, dsm, _didx, dw):
         scores, sm, idx, w = ctx.saved_tensors
-        K, mode, rb = ctx.cfg
+        K, mode, rb, param = ctx.cfg
         dsm = None if dsm is None else dsm.contiguous().float()
         dw = None if dw is None else dw.contiguous().float()
-        ds = ops.router_select_bwd(scores, K, mode, rb, sm, idx, w, dw, dsm)
-        return ds, None, None, None
+        ds = ops.router_select_bwd(scores, K, mode, rb, sm, idx, w, dw, dsm, param=param)
+        return ds, None, None, None, None
 
 
 class RouterAux(torch.autograd.Function):
@@ -557,19 +558,21 @@ class DenseFFN(torch.autograd.Function):
 
 # ======================================================================================================== affinity
 class SoftplusMean(torch.autograd.Function):
-    """aff[r] = mean_d softplus(y[r,d]) in y.dtype -- `torch.mean(F.softplus(out_i), dim=-1)`
-    (moe_model/model/moe/competesmoe.py:242; pretrain competesmoe.py:401)."""
+    """aff[r] = mean_d softplus(y[r,d]) -- `torch.mean(F.softplus(out_i), dim=-1)` (moe_model/model/moe/competesmoe.py:242;
+    pretrain competesmoe.py:401).  In y.dtype for the LLaVA stack (x.dtype tensor ops); `fp32_affinity` for the pretrain stack under
+    CUDA autocast, where F.softplus is on the fp32 cast list: fp32 softplus / mean of the bf16 expert outputs, fp32 affinities."""
 
     @staticmethod
-    def forward(ctx, y2):
+    def forward(ctx, y2, fp32_affinity: bool = False):
         y2 = y2.contiguous()
         ctx.save_for_backward(y2)
-        return ops.softplus_mean(y2)
+        ctx.aff_dtype = torch.float32 if fp32_affinity else y2.dtype
+        return ops.softplus_mean(y2, ctx.aff_dtype)
 
     @staticmethod
     def backward(ctx, daff):
         (y2,) = ctx.saved_tensors
-        return ops.softplus_mean_bwd(y2, daff.contiguous().to(y2.dtype))
+        return ops.softplus_mean_bwd(y2, daff.contiguous().to(ctx.aff_dtype)), None
 
 
 # ======================================================================================================== diversity loss

@@ -2,6 +2,7 @@
 current HIP stream.  No math happens here."""
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -89,21 +90,21 @@ def gate_logits(x2: torch.Tensor, w_gate: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def router_select(scores: torch.Tensor, K: int, mode: int, round_sum_bf16: bool, want_softmax: bool = True):
+def router_select(scores: torch.Tensor, K: int, mode: int, round_sum_bf16: bool, want_softmax: bool = True, param: float = 1.0):
     _need_cuda(scores)
     T, E = scores.shape
     sm = torch.empty(T, E, dtype=torch.float32, device=scores.device) if want_softmax else None
     idx = torch.empty(T, K, dtype=torch.int32, device=scores.device)
     w = torch.empty(T, K, dtype=torch.float32, device=scores.device)
-    L.check(lib.csmoe_router_select(scores.data_ptr(), _dt(scores), T, E, K, mode, int(round_sum_bf16), _ptr(sm),
+    L.check(lib.csmoe_router_select(scores.data_ptr(), _dt(scores), T, E, K, mode, int(round_sum_bf16), float(param), _ptr(sm),
                                     idx.data_ptr(), w.data_ptr(), _stream()), "router_select")
     return sm, idx, w
 
 
-def router_select_bwd(scores, K, mode, round_sum_bf16, sm, idx, w, dw, dsm):
+def router_select_bwd(scores, K, mode, round_sum_bf16, sm, idx, w, dw, dsm, param: float = 1.0):
     T, E = scores.shape
     out = torch.empty_like(scores)
-    L.check(lib.csmoe_router_select_bwd(scores.data_ptr(), _dt(scores), T, E, K, mode, int(round_sum_bf16), _ptr(sm),
+    L.check(lib.csmoe_router_select_bwd(scores.data_ptr(), _dt(scores), T, E, K, mode, int(round_sum_bf16), float(param), _ptr(sm),
                                         idx.data_ptr(), w.data_ptr(), _ptr(dw), _ptr(dsm), out.data_ptr(), _stream()),
             "router_select_bwd")
     return out
@@ -458,18 +459,22 @@ def dense_colsum(G: torch.Tensor, out_dtype=None) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ affinity
-def softplus_mean(y: torch.Tensor) -> torch.Tensor:
+SOFTPLUS_PRECISE = os.environ.get("CSMOE_SOFTPLUS_PRECISE", "1") != "0"    # exp / log1p as torch evaluates them (A/B: 0 = hardware exp / log)
+
+
+def softplus_mean(y: torch.Tensor, aff_dtype=None) -> torch.Tensor:
+    """aff_dtype: y.dtype (x.dtype tensor-op semantics) or torch.float32 around bf16 rows (CUDA-autocast semantics)."""
     R, D = y.shape
-    aff = torch.empty(R, dtype=y.dtype, device=y.device)
-    L.check(lib.csmoe_softplus_mean(y.data_ptr(), aff.data_ptr(), R, D, _dt(y), _stream()), "softplus_mean")
+    aff = torch.empty(R, dtype=aff_dtype or y.dtype, device=y.device)
+    L.check(lib.csmoe_softplus_mean(y.data_ptr(), aff.data_ptr(), R, D, _dt(y), _dt(aff), int(SOFTPLUS_PRECISE), _stream()), "softplus_mean")
     return aff
 
 
 def softplus_mean_bwd(y: torch.Tensor, daff: torch.Tensor, dy_add: Optional[torch.Tensor] = None) -> torch.Tensor:
     R, D = y.shape
     dy = torch.empty_like(y)
-    L.check(lib.csmoe_softplus_mean_bwd(y.data_ptr(), daff.data_ptr(), _ptr(dy_add), dy.data_ptr(), R, D, _dt(y), _stream()),
-            "softplus_mean_bwd")
+    L.check(lib.csmoe_softplus_mean_bwd(y.data_ptr(), daff.data_ptr(), _ptr(dy_add), dy.data_ptr(), R, D, _dt(y), _dt(daff),
+                                        int(SOFTPLUS_PRECISE), _stream()), "softplus_mean_bwd")
     return dy
 
 

@@ -5,7 +5,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from .. import _lib as L
-from ..functional import DenseFFN, RouterSelect, SoftplusMean
+from ..functional import DenseFFN, DiversityLoss, RouterSelect, SoftplusMean
 from .moe import MoE, op_dtype
 from .register import register_moe
 
@@ -103,11 +103,13 @@ class CompeteSMoE(MoE):
             "Can not active  both  Cosine and Norm Weigh. Just use one method - Cosine or Norm Weigh to Normalization"
         gate_logits = self.compute_gate(x)
         if getattr(self.args, "norm_sigmoid", False):
-            gate_softmax = F.softmax(gate_logits, dim=-1, dtype=torch.float32)
-            w, idx = torch.topk(gate_logits, self.num_selected)
-            w = torch.sigmoid(w / getattr(self.args, "scale_weight", 1.0))
-            w = w / torch.sum(w, dim=-1, keepdim=True).to(self._stream_dtype or x.dtype)
-            return w, idx.int(), gate_softmax, gate_logits
+            # top-k of the logits, sigmoid(v / scale_weight), renormalised (:476-483): same kernel and tie rule as every other router
+            shp = gate_logits.shape
+            xd = self._stream_dtype or x.dtype
+            sm, idx, w = RouterSelect.apply(gate_logits.reshape(-1, shp[-1]), self.num_selected, L.SEL_TOPK_SIGMOID,
+                                            xd == torch.bfloat16, float(getattr(self.args, "scale_weight", 1.0)))
+            K = self.num_selected
+            return w.view(*shp[:-1], K), idx.view(*shp[:-1], K), sm.view(shp), gate_logits
         weights, selected_experts, gate_softmax = self.topk_expert(gate_logits, x.dtype)
         return weights, selected_experts, gate_softmax, gate_logits
 
@@ -118,7 +120,11 @@ class CompeteSMoE(MoE):
         op = op_dtype(x)
         x2 = x.reshape(-1, D).to(op)
         outs = [DenseFFN.apply(x2, self.keys[e], None, self.values[e], None, self.act_code, L.B_KN) for e in range(self.n_experts)]
-        aff = torch.stack([SoftplusMean.apply(o) for o in outs], dim=-1)                 # [T,E] op dtype
+        # under CUDA autocast F.softplus is an fp32-policy op: fp32 softplus / mean / affinities from the bf16 expert outputs, top-K
+        # and the renormalised weights on fp32 scores (the reference trains this way, simple_task.py:295); outside autocast the ops
+        # stay in the operand dtype
+        fp32_aff = op == torch.bfloat16 and torch.is_autocast_enabled("cuda")
+        aff = torch.stack([SoftplusMean.apply(o, fp32_aff) for o in outs], dim=-1)       # [T,E] fp32 (autocast) / op dtype
         asm, idx, w = RouterSelect.apply(aff, self.num_selected, L.SEL_RAW, False)
         eo = torch.stack(outs, dim=1).view(B, N, self.n_experts, -1)
         idx_l = idx.view(B, N, -1).long()
@@ -129,12 +135,17 @@ class CompeteSMoE(MoE):
         return F.mse_loss(gate_softmax, affinity_softmax)
 
     def experts_diversity_loss(self, expert_outputs):
+        """Mean over T*K*K of the off-diagonal cosine similarities (:330-372) -- `csmoe_pair_cosine`, fp32 norms and dots of the
+        expert outputs as stored.  (Under autocast upstream normalises in fp32 and runs the K x K bmm in bf16; the kernel keeps the
+        fp32 dots.)  `nb_diver` counts the non-zero entries upstream and is never read back; K <= 8 here."""
         eo = expert_outputs
+        if eo.dim() == 5:
+            eo = eo.reshape(eo.shape[0], eo.shape[1] * eo.shape[2], *eo.shape[3:])
         B, N, K, D = eo.shape
-        nrm = F.normalize(eo, p=2, dim=-1).view(B * N, K, D)
-        sim = torch.bmm(nrm, nrm.transpose(1, 2)) * (1 - torch.eye(K, device=eo.device, dtype=eo.dtype))
-        self.nb_diver += (sim != 0).sum()
-        return sim.mean()
+        if K > 8:
+            raise NotImplementedError("competesmoe_amd: diversity loss supports at most 8 selected experts")
+        self.nb_diver += B * N * K * (K - 1)
+        return DiversityLoss.apply(eo)
 
     def compute_moe_main(self, x, selected_experts, weights):
         return self.ffn(x, selected_experts, weights)

@@ -146,7 +146,10 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         # `relu_pass_rate` every log_interval iterations (compute_scores, moe.py:406-414; upstream tests the bound method
         # `self.train`, which is always true, so evaluation logs too)
         stats = {} if (keys is None and self.log_interval is not None and self.iter % self.log_interval == 0) else None
-        out = MoEFFNPacked.apply(x2, weights.reshape(-1, K).float().contiguous(),
+        wk = weights.reshape(-1, K)
+        if op == torch.bfloat16:      # `reduction_weight.type_as(res) @ res` (cvmm.py:483, :499): the K weights enter as bf16 values
+            wk = wk.to(op)
+        out = MoEFFNPacked.apply(x2, wk.float().contiguous(),
                                  selected_experts.reshape(-1, K).int().contiguous(),
                                  self.keys if keys is None else keys, self.values if values is None else values,
                                  self.bias if bias is None else bias, None, self.act_code, L.COMBINE_DOT, res, stats)

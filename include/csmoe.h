@@ -35,7 +35,9 @@ enum {
   CSMOE_SEL_SOFTMAX = 0,  /* softmax(fp32) -> topk -> w/sum          moe_model/model/moe/moe.py:129-130, smoe.py:44      */
   CSMOE_SEL_RAW = 1,      /* topk on raw scores -> w/sum (competition) moe_model/model/moe/competesmoe.py:253-255          */
   CSMOE_SEL_TOPK_SOFTMAX = 2, /* topk(logits) -> softmax over the K  moe_pretrain_model/layers/moe/deepseekv2.py:140-142 */
-  CSMOE_SEL_SIGMOID = 3   /* topk(sigmoid) -> w/(sum+1e-20)           moe_pretrain_model/layers/moe/deepseekv3.py:147-151 */
+  CSMOE_SEL_SIGMOID = 3,  /* topk(sigmoid) -> w/(sum+1e-20)           moe_pretrain_model/layers/moe/deepseekv3.py:147-151 */
+  CSMOE_SEL_TOPK_SIGMOID = 4 /* topk(logits) -> sigmoid(v / sel_param) -> w/sum   (`norm_sigmoid` + `scale_weight`,
+                                moe_pretrain_model/layers/moe/competesmoe.py:476-483)                                    */
 };
 
 /* Combine rounding rule. */
@@ -78,15 +80,16 @@ int csmoe_gate_logits(const void* x, const void* w_gate, void* logits, int T, in
 /* scores[T,E] (dtype) -> softmax[T,E] fp32 (of the scores), idx[T,K] int32 (descending value, ties ->
  * lowest index), w[T,K] fp32.  `round_sum_bf16` != 0 rounds the K-sum to bf16 before the division
  * (`.to(x.dtype)` on the denominator, smoe.py:44).  softmax may be null for SEL_TOPK_SOFTMAX/SIGMOID.
+ * `sel_param`: the scale of SEL_TOPK_SIGMOID (args.scale_weight), ignored by the other rules.
  * replaces topk_expert + renorm (moe_model/model/moe/moe.py:113-132; smoe.py:19-44;
  * competesmoe.py:246-255; pretrain smoe.py:123-143, deepseekv2.py:140-142, deepseekv3.py:147-151). */
 int csmoe_router_select(const void* scores, int dtype, int T, int E, int K, int sel_mode, int round_sum_bf16,
-                        float* softmax, int32_t* idx, float* w, csmoe_stream_t stream);
+                        float sel_param, float* softmax, int32_t* idx, float* w, csmoe_stream_t stream);
 
 /* backward of csmoe_router_select: given dw[T,K] (fp32) and optional dsoftmax[T,E] (fp32, from the aux
  * losses), produce dscores[T,E] in `dtype`.  (autograd of the same reference lines.) */
 int csmoe_router_select_bwd(const void* scores, int dtype, int T, int E, int K, int sel_mode, int round_sum_bf16,
-                            const float* softmax, const int32_t* idx, const float* w, const float* dw,
+                            float sel_param, const float* softmax, const int32_t* idx, const float* w, const float* dw,
                             const float* dsoftmax, void* dscores, csmoe_stream_t stream);
 
 /* ---- binning -----------------------------------------------------------------------------------------
@@ -233,11 +236,16 @@ int csmoe_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slo
                             int D, csmoe_stream_t stream);
 
 /* ---- competition affinity ----------------------------------------------------------------------------
- * aff[r] = mean_d softplus(y[r, d]) rounded to dtype  (competesmoe.py:242; pretrain competesmoe.py:401) and its
- * backward dy[r,d] = round(daff[r] / D * sigmoid(y[r,d])) (+ dy_add if non-null). */
-int csmoe_softplus_mean(const void* y, void* aff, int R, int D, int dtype, csmoe_stream_t stream);
-int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype,
-                            csmoe_stream_t stream);
+ * aff[r] = mean_d softplus(y[r, d])  (competesmoe.py:242; pretrain competesmoe.py:401) and its backward
+ * dy[r,d] = round(daff[r] / D * sigmoid(y[r,d])) (+ dy_add if non-null).
+ * `aff_dtype` == `dtype`: the LLaVA stack's x.dtype tensor ops (every softplus value rounded to dtype before the mean, the mean
+ * rounded to dtype).  `aff_dtype` == CSMOE_F32 around bf16 rows: the pretrain stack under CUDA autocast, where F.softplus is an
+ * fp32-policy op (simple_task.py:295 + torch's autocast table): softplus, mean and the affinities are fp32, daff is fp32 and the
+ * gradient is rounded to bf16 once.  `precise` != 0 evaluates exp / log1p as torch does instead of with the hardware
+ * approximations. */
+int csmoe_softplus_mean(const void* y, void* aff, int R, int D, int dtype, int aff_dtype, int precise, csmoe_stream_t stream);
+int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype, int aff_dtype,
+                            int precise, csmoe_stream_t stream);
 
 #ifdef __cplusplus
 }

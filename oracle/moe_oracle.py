@@ -6,8 +6,10 @@ may import this module, and only as the checker / the timed CPU baseline.  The s
 (`competesmoe_amd`) never imports it and fails loudly when its HIP library is missing.
 
 Pinned by: `tests/golden/*.pt`, produced by running the reference classes themselves in the build
-container (`tests/golden/make_golden_{llava,pretrain}.py`); `tests/test_oracle_golden.py` checks every
-function below against them.  The reference has no unit tests / golden vectors of its own for this
+container (`tests/golden/make_golden_{llava,pretrain,block,pretrain_block}.py`; the pretrain fixtures run the
+reference's own Triton cvmm kernels under the Triton interpreter and, for bf16, the CUDA autocast policy the
+reference trains under -- tests/golden/ref_env.py); `tests/test_oracle_golden.py` checks every function below
+against them.  The reference has no unit tests / golden vectors of its own for this
 path, so those captured outputs are the pin.
 
 Every function cites the reference file:line it restates (paths relative to the reference root).
@@ -99,8 +101,8 @@ def entropy_balance(logits: torch.Tensor) -> torch.Tensor:
     """moe_pretrain_model/layers/moe/moe.py:323-332 with framework/utils/entropy.py:21-22 and
     distributed_ops.py:47-58 (non-distributed branch): -H(logmeanexp_n log_softmax(logits)), mean over batch."""
     sel = logits.flatten(1, -2)
-    ls = F.log_softmax(sel, dim=-1)
-    lm = ls.float().logsumexp(-2) - math.log(ls.shape[-2])
+    ls = F.log_softmax(sel.float(), dim=-1)      # bf16 logits under CUDA autocast: log_softmax is an fp32-policy op
+    lm = ls.logsumexp(-2) - math.log(ls.shape[-2])
     ent = -(lm * lm.exp()).sum(-1)
     return -ent.mean()
 
@@ -307,11 +309,10 @@ def bin_tokens(sel: torch.Tensor, n_experts: int):
     return counts, offsets, perm
 
 
-def cvmm_ref(x, sel_sorted, in_index, out_index, keys, op_dtype, reduction_weight=None):
-    """cvmm.py:99-168, 363-398: out[out_index[m]] = x[in_index[m]] @ keys[sel_sorted[m]] (operands in op dtype,
-    fp32 accumulate, rounded to op dtype); optional weighted K-reduction as a [..,1,K]@[..,K,D] bmm (:481-483)."""
-    xf = x.flatten(end_dim=-2)
-    rows = xf[in_index.long()].to(op_dtype)
+def _cvmm_rows(x2, in_index, sel_sorted, keys, out_index, op_dtype):
+    """cvmm_kernel (cvmm.py:61-168): out[out_index[m]] = round_op(x2[in_index[m]] @ keys[sel_sorted[m]]), operands cast to the op
+    dtype per tile, fp32 accumulate.  x2 [R, Din], keys [E, Din, Dout] -> [M, Dout] in the op dtype."""
+    rows = x2[in_index.long()].to(op_dtype)
     M, Dout = in_index.shape[0], keys.shape[-1]
     prod = torch.zeros(M, Dout, dtype=op_dtype)
     ss = sel_sorted.flatten().long()
@@ -319,12 +320,66 @@ def cvmm_ref(x, sel_sorted, in_index, out_index, keys, op_dtype, reduction_weigh
         m = (ss == e).nonzero().squeeze(-1)
         if m.numel():
             prod = prod.index_put((m,), (rows[m].float() @ keys[e].to(op_dtype).float()).to(op_dtype))
-    out = torch.zeros(M, Dout, dtype=op_dtype).index_put((out_index.long(),), prod)
-    if reduction_weight is not None:
-        w = reduction_weight
-        out = out.view(*w.shape, Dout)
-        out = (w.unsqueeze(-2).type_as(out) @ out).squeeze(-2)
-    return out
+    return torch.zeros(M, Dout, dtype=op_dtype).index_put((out_index.long(),), prod)
+
+
+class _CvmmFn(torch.autograd.Function):
+    """CVMM.forward / CVMM.backward (cvmm.py:460-551) restated with the reference's rounding points: the op dtype is the autocast
+    dtype (bf16) or fp32; the K weights enter as op-dtype values (`type_as`); the weight gradient multiplies op-dtype operands
+    into an fp32 (master dtype) accumulator (cvmm_backward_kernel3, :194-345); the input gradient is the UNSCALED grouped product
+    rounded to the op dtype, then scaled by the op-dtype weights (:538-547)."""
+
+    @staticmethod
+    def forward(ctx, x, sel_sorted, in_index, out_index, keys, reduction_weight, op_dtype):
+        ctx.save_for_backward(x, keys, sel_sorted, in_index, out_index, reduction_weight)
+        ctx.op = op_dtype
+        x2 = x.flatten(end_dim=-2)
+        res = _cvmm_rows(x2, in_index, sel_sorted, keys, in_index if out_index is None else out_index, op_dtype)
+        if reduction_weight is not None:
+            w = reduction_weight
+            res = res.view(*w.shape, res.shape[-1])
+            res = (w.unsqueeze(-2).type_as(res) @ res).squeeze(-2)
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        x, keys, sel_sorted, in_index, out_index, w = ctx.saved_tensors
+        op = ctx.op
+        gw = (w.unsqueeze(-1).type_as(g) @ g.unsqueeze(-2)) if w is not None else g
+        # weight gradient (cvmm_triton_backward, :421-457): A = x rows by sel_index, B = grad rows by out_index (or sel_index)
+        x2 = x.flatten(end_dim=-2)
+        g2 = gw.flatten(end_dim=-2)
+        a = x2[in_index.long()].to(op).float()
+        b = g2[(in_index if out_index is None else out_index).long()].to(op).float()
+        ss = sel_sorted.flatten().long()
+        gk = torch.zeros(keys.shape, dtype=torch.float32)
+        for e in range(keys.shape[0]):
+            m = (ss == e).nonzero().squeeze(-1)
+            if m.numel():
+                gk[e] = a[m].t() @ b[m]
+        gk = gk.to(keys.dtype)
+        # input gradient (:519-549)
+        bw_index = in_index if out_index is None else out_index
+        bw_out = bw_index
+        if w is not None:
+            bw_index = bw_index // w.shape[-1]
+        gxf = _cvmm_rows(g.flatten(end_dim=-2), bw_index, sel_sorted, keys.transpose(1, 2), bw_out, op)
+        gxf = gxf.view(*x.shape[:-1], -1, x.shape[-1])
+        gwo = None
+        if w is not None:
+            gx = (w.view(*gxf.shape[:-1]).unsqueeze(-2).type_as(gxf) @ gxf).squeeze(-2)
+            gwo = (gxf.type_as(w) @ x.unsqueeze(-1).type_as(w)).squeeze(-1).view_as(w)
+        elif gxf.shape[-2] != 1:
+            gx = gxf.sum(-2)
+        else:
+            gx = gxf
+        return gx.view_as(x).to(x.dtype), None, None, None, gk, gwo, None
+
+
+def cvmm_ref(x, sel_sorted, in_index, out_index, keys, op_dtype, reduction_weight=None):
+    """`cvmm(x, sel, keys)` (cvmm.py:555-577) for a CVMMSel(sel=sel_sorted, sel_index=in_index, out_index=out_index (may be None),
+    reduction_weight).  Forward AND backward follow the reference's kernels / autograd function (see _CvmmFn)."""
+    return _CvmmFn.apply(x, sel_sorted, in_index, out_index, keys, reduction_weight, op_dtype)
 
 
 def pretrain_ffn(x, idx, weights, keys, values, act, op_dtype, bias=None, o_bias=None):
@@ -338,20 +393,25 @@ def pretrain_ffn(x, idx, weights, keys, values, act, op_dtype, bias=None, o_bias
     if bias is not None:
         scores = scores + bias[idx.long()]
     scores = ACTS[act](scores)
-    out = cvmm_ref(scores, ssel, perm, perm, values, op_dtype, reduction_weight=weights)
+    # second call (smoe.py:240-248): reduction_weight = weights, sel_index <- out_index, out_index <- None
+    out = cvmm_ref(scores, ssel, perm, None, values, op_dtype, reduction_weight=weights)
     out = out.view(B, N, -1)
     if o_bias is not None:
         out = out + o_bias
     return out
 
 
-def pretrain_dense_affinity(x, keys, values, act, k, x_dtype):
-    """competition_policy_mlp_faster (pretrain competesmoe.py:381-414)."""
+def pretrain_dense_affinity(x, keys, values, act, k, x_dtype, op_dtype=None):
+    """competition_policy_mlp_faster (pretrain competesmoe.py:381-414).  `op_dtype` = torch.bfloat16 restates the run under CUDA
+    autocast (simple_task.py:295): both matmuls cast their operands to bf16 and return bf16; F.softplus is an fp32-policy op, so
+    softplus, mean, the affinities, the top-k and the renormalised weights are fp32."""
     B, N, D = x.shape
-    eo = torch.matmul(x.view(-1, D), keys)
+    if op_dtype is not None:
+        x, keys, values = x.to(op_dtype), keys.to(op_dtype), values.to(op_dtype)
+    eo = torch.matmul(x.reshape(-1, D), keys)
     eo = ACTS[act](eo)
     eo = torch.matmul(eo, values).transpose(1, 0)        # [T,E,D]
-    aff = torch.mean(F.softplus(eo), dim=-1).view(B, N, -1)
+    aff = torch.mean(F.softplus(eo.float() if op_dtype is not None else eo), dim=-1).view(B, N, -1)
     asm = F.softmax(aff, dim=-1, dtype=torch.float32)
     idx = topk_lowest_index(aff.detach(), k)[1]
     w = torch.gather(aff, -1, idx)
@@ -361,6 +421,22 @@ def pretrain_dense_affinity(x, keys, values, act, k, x_dtype):
     return w, idx, asm, aff, topk_out
 
 
+def pretrain_diversity_loss(topk_out: torch.Tensor, op_dtype=None) -> torch.Tensor:
+    """experts_diversity_loss of the pretrain stack (pretrain competesmoe.py:330-372): F.normalize -> bmm -> zeroed diagonal ->
+    mean, WITHOUT the LLaVA stack's `.to(float32)`.  Under CUDA autocast (`op_dtype` = bf16): `norm` is an fp32-policy op, so the
+    bf16 outputs are normalised in fp32; `bmm` is a lower-precision op, so the fp32 unit vectors are rounded to bf16 and the K x K
+    products come back in bf16; the fp32 mask promotes them to fp32 for the mean."""
+    eo = topk_out
+    B, N, K, D = eo.shape
+    if op_dtype is not None and eo.dtype == op_dtype and op_dtype != torch.float32:
+        denom = eo.float().norm(2, -1, keepdim=True).clamp_min(1e-12).expand_as(eo)
+        nrm = (eo / denom).view(B * N, K, D).to(op_dtype)
+    else:
+        nrm = F.normalize(eo, p=2, dim=-1).view(B * N, K, D)
+    sim = torch.bmm(nrm, nrm.transpose(1, 2)) * (1 - torch.eye(K))
+    return sim.mean()
+
+
 def pretrain_deepseek_forward(x, w_gate, keys, values, keys_shared, values_shared, k, mode: str, op_dtype, x_dtype):
     """DeepSeekV2.forward (moe_pretrain_model/layers/moe/deepseekv2.py:135-181: top-k of the logits, softmax over the K)
     and DeepSeekV3.forward (deepseekv3.py:142-190: top-k of sigmoid(logits), w / (sum + 1e-20)), both plus the always-on shared
@@ -368,14 +444,15 @@ def pretrain_deepseek_forward(x, w_gate, keys, values, keys_shared, values_share
     B, N, D = x.shape
     xx = x.to(op_dtype)
     lg = F.linear(xx, w_gate.to(op_dtype))
+    # bf16 logits = the run under CUDA autocast: softmax and sum are fp32-policy ops there, sigmoid is not
     if mode == "deepseekv2":
         idx = topk_lowest_index(lg.detach().float(), k)[1]
-        w = F.softmax(torch.gather(lg, -1, idx), dim=-1).to(x_dtype)
+        w = F.softmax(torch.gather(lg, -1, idx).float(), dim=-1).to(x_dtype)
     else:
         sg = torch.sigmoid(lg)
         idx = topk_lowest_index(sg.detach().float(), k)[1]
         w = torch.gather(sg, -1, idx)
-        w = w / (w.sum(dim=-1, keepdim=True) + 1e-20)
+        w = w / (w.float().sum(dim=-1, keepdim=True) + 1e-20)
     out = pretrain_ffn(x, idx, w, keys, values, "relu", op_dtype)
     zero = torch.zeros(B, N, 1, dtype=torch.long)
     one = torch.ones(B, N, 1)

@@ -1,117 +1,36 @@
 #!/usr/bin/env python3
-"""Generate golden vectors for the LM-pretrain-stack MoE layers by RUNNING THE REFERENCE classes.
+"""Generate golden vectors for the LM-pretrain-stack MoE layers by RUNNING THE REFERENCE classes AND ITS TRITON KERNELS.
 
-Build-container only (needs /root/reference).  The pretrain package does not import as shipped
-(circular import + missing files), so this script builds stub *packages* in
-sys.modules whose __path__ points into the reference, loads the three mixins, the entropy /
-distributed_ops helpers and layers/cvmm.py by file path, and then imports
-layers.moe.{register,moe,smoe,competesmoe,deepseekv2,deepseekv3} normally.
-
-The two Triton kernels in layers/cvmm.py cannot run without a GPU.  `cvmm()` is therefore
-replaced by `cvmm_cpu` below -- OUR restatement of the documented index semantics
-(cvmm.py:99-168, 363-398, 481-483) with plain torch ops -- before the layer modules are imported.
-Everything else (gating, top-k, index preparation `cvmm_prepare_sel2`, losses, schedule, mixins)
-is the reference's own code.  The fixtures say so in meta["cvmm"].
+Build-container only (needs /root/reference).  tests/golden/ref_env.py sets up the environment: stub packages so the pretrain
+package imports, the reference's own `cvmm()` / `CVMM` autograd function / `cvmm_kernel` /
+`cvmm_backward_kernel3` executed by the Triton interpreter on CPU (one configuration of each kernel's own autotune list, no
+benchmarking), and -- for the bf16 cases -- the CUDA autocast policy the reference trains under (simple_task.py:295)
+reproduced on CPU tensors.  Gating, top-k, index preparation, both cvmm calls and their backward, losses, schedule and mixins
+are all the reference's own code; nothing on the path is restated here.  meta["cvmm"] / meta["autocast_fp32_upcasts"] record
+how each fixture was made.
 
 Usage:  python tests/golden/make_golden_pretrain.py   (writes tests/golden/pretrain_*.pt)
 """
-import importlib
-import importlib.util
+import contextlib
 import os
 import sys
 import tempfile
 import types
 
-import torch
-import torch.nn.functional as F
-
 HERE = os.path.dirname(os.path.abspath(__file__))
-REF = "/root/reference/moe_pretrain_model"
+sys.path.insert(0, HERE)
+import ref_env  # noqa: E402  (sets TRITON_INTERPRET=1 before triton is imported)
 
-_CVMM_OUT_DTYPE = [torch.float32]   # emulates cvmm.get_dtype(): autocast dtype or fp32
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
-
-def _load(name, path):
-    spec = importlib.util.spec_from_file_location(name, path)
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules[name] = mod
-    spec.loader.exec_module(mod)
-    return mod
+REF = ref_env.REF
+_load, _pkg = ref_env._load, ref_env._pkg
+_import_reference = ref_env.import_reference
 
 
-def _pkg(name, path):
-    m = types.ModuleType(name)
-    m.__path__ = [path]
-    sys.modules[name] = m
-    return m
-
-
-def cvmm_cpu(x, sel, keys):
-    """CPU restatement of reference cvmm(): out[out_index[m]] = x[sel_index[m]] @ keys[sel[m]],
-    operands cast to the op dtype, fp32 accumulate, optional weighted K-reduction."""
-    op = _CVMM_OUT_DTYPE[0]
-    xf = x.flatten(end_dim=-2)
-    ssel = sel.sel.flatten().long()
-    rows = xf[sel.sel_index.long()].to(op)
-    M, Dout = ssel.shape[0], keys.shape[-1]
-    prod = torch.zeros(M, Dout, dtype=op)
-    for e in range(keys.shape[0]):
-        msk = ssel == e
-        if msk.any():
-            acc = rows[msk].float() @ keys[e].to(op).float()
-            prod = prod.index_put((msk.nonzero().squeeze(-1),), acc.to(op))
-    dst = sel.sel_index if sel.out_index is None else sel.out_index
-    out = torch.zeros(M, Dout, dtype=op).index_put((dst.long(),), prod)
-    out = out.view(*sel.sel.shape, Dout)
-    if sel.reduction_weight is not None:
-        w = sel.reduction_weight
-        out = out.view(*w.shape, Dout)
-        out = (w.unsqueeze(-2).type_as(out) @ out).squeeze(-2)
-    return out
-
-
-def _import_reference():
-    if "layers.moe.smoe" in sys.modules:
-        return sys.modules["layers.moe.register"].get_moe
-    fw = _pkg("framework", os.path.join(REF, "framework"))
-    fwl = _pkg("framework.layers", os.path.join(REF, "framework", "layers"))
-    fwu = _pkg("framework.utils", os.path.join(REF, "framework", "utils"))
-
-    # minimal stand-in for framework.utils.U (only apply_to_tensors is used by LoggingLayer.log)
-    U = types.ModuleType("framework.utils.U")
-
-    def apply_to_tensors(d, fn):
-        if torch.is_tensor(d):
-            return fn(d)
-        if isinstance(d, (list, tuple)):
-            return type(d)(apply_to_tensors(v, fn) for v in d)
-        if isinstance(d, dict):
-            return {k: apply_to_tensors(v, fn) for k, v in d.items()}
-        return d
-    U.apply_to_tensors = apply_to_tensors
-    fwu.U = U
-    ent = _load("framework.utils.entropy", os.path.join(REF, "framework", "utils", "entropy.py"))
-    dops = _load("framework.utils.distributed_ops", os.path.join(REF, "framework", "utils", "distributed_ops.py"))
-    for k in ("entropy", "entropy_l", "relative_perplexity", "relative_perplexity_l", "perplexity"):
-        setattr(fwu, k, getattr(ent, k))
-    fwu.distributed_ops = dops
-    fwu.entropy = ent.entropy
-    fw.utils = fwu
-    ll = _load("framework.layers.logging_layer", os.path.join(REF, "framework", "layers", "logging_layer.py"))
-    rl = _load("framework.layers.regularized_layer", os.path.join(REF, "framework", "layers", "regularized_layer.py"))
-    ol = _load("framework.layers.once_per_iter_layer", os.path.join(REF, "framework", "layers", "once_per_iter_layer.py"))
-    fwl.LoggingLayer, fwl.RegularizedLayer, fwl.OncePerIterLayer = ll.LoggingLayer, rl.RegularizedLayer, ol.OncePerIterLayer
-    fw.layers = fwl
-
-    lay = _pkg("layers", os.path.join(REF, "layers"))
-    cv = _load("layers.cvmm", os.path.join(REF, "layers", "cvmm.py"))
-    cv.cvmm = cvmm_cpu
-    lay.cvmm = cvmm_cpu
-    lay.cvmm_prepare_sel = cv.cvmm_prepare_sel
-    _pkg("layers.moe", os.path.join(REF, "layers", "moe"))
-    for m in ("register", "moe", "smoe", "competesmoe", "deepseekv2", "deepseekv3"):
-        importlib.import_module(f"layers.moe.{m}")
-    return sys.modules["layers.moe.register"].get_moe
+def amp(bf16, log):
+    return ref_env.cuda_autocast_bf16(log) if bf16 else contextlib.nullcontext()
 
 
 def make_args(**kw):
@@ -143,7 +62,8 @@ def run_case(name, moe_name, bf16, *, B=2, N=64, D=64, E=8, F_=32, K=2, competit
                     p.data = torch.randn(p.shape, generator=g0) * 0.1
         fx = {"meta": dict(name=name, moe_name=moe_name, bf16=bf16, B=B, N=N, D=D, E=E, F=F_, K=K, bias=bias,
                            competition=competition, args=vars(args),
-                           cvmm="cvmm() replaced by a CPU restatement in make_golden_pretrain.py (Triton needs a GPU)")}
+                           cvmm=ref_env.CVMM_META)}
+        upcasts = {}
         kw = {}
         if moe_name == "competesmoe":
             torch.manual_seed(1234)
@@ -163,14 +83,9 @@ def run_case(name, moe_name, bf16, *, B=2, N=64, D=64, E=8, F_=32, K=2, competit
         else:
             fx["x_seed"] = seed + 1
 
-        _CVMM_OUT_DTYPE[0] = torch.bfloat16 if bf16 else torch.float32
         xg = x.clone().requires_grad_(True)
         layer.regularization_present = True
-        if bf16:
-            with torch.autocast("cpu", dtype=torch.bfloat16):
-                out = layer(xg, **kw)
-                reg = layer.get_reg_loss()
-        else:
+        with amp(bf16, upcasts):
             out = layer(xg, **kw)
             reg = layer.get_reg_loss()
         fx["output"] = out.detach().clone()
@@ -184,21 +99,16 @@ def run_case(name, moe_name, bf16, *, B=2, N=64, D=64, E=8, F_=32, K=2, competit
             fx["x_grad_sum"] = xg.grad.double().sum()
             fx["x_grad_norm"] = xg.grad.double().norm()
             fx["grad_norms"] = {k: p.grad.double().norm() for k, p in layer.named_parameters() if p.grad is not None}
-        with torch.no_grad():
+        with torch.no_grad(), amp(bf16, upcasts):
             gl = layer.compute_gate(x)
             fx["gate_logits"] = gl.clone()
             if competition:
-                _CVMM_OUT_DTYPE[0] = torch.bfloat16 if bf16 else torch.float32
-                if bf16:
-                    with torch.autocast("cpu", dtype=torch.bfloat16):
-                        aw, aidx, asm, aff, _ = layer.competition_policy_mlp_faster(x)
-                else:
-                    aw, aidx, asm, aff, _ = layer.competition_policy_mlp_faster(x)
+                aw, aidx, asm, aff, _ = layer.competition_policy_mlp_faster(x)
                 fx["aff_weights"], fx["aff_selected"] = aw.clone(), aidx.clone()
                 fx["aff_softmax"], fx["aff_scores"] = asm.clone(), aff.clone()
+        fx["meta"]["autocast_fp32_upcasts"] = dict(upcasts)
     finally:
         os.chdir(cwd)
-        _CVMM_OUT_DTYPE[0] = torch.float32
     path = os.path.join(HERE, f"pretrain_{name}.pt")
     torch.save(fx, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB | out", tuple(out.shape),

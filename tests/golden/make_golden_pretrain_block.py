@@ -6,10 +6,10 @@ Build container only (needs /root/reference; imported, never copied).  Same stub
 package does not import as shipped), plus: `layers.moe_layer` (absent upstream MoE class the transformer file
 imports by name only), `wandb` and `framework.visualize.plot.CustomPlot` (imported by full_moe_relative_attention.py, never used
 here: moe_attention=False) as empty stand-ins, and
-`cvmm()` replaced by the CPU restatement of make_golden_pretrain.py (the Triton kernels need a GPU).
+the reference's own Triton cvmm kernels run by the Triton interpreter (tests/golden/ref_env.py).
 
-The whole pre-LN transformer layer (rope attention half included) runs on CPU, in fp32 and under bf16 autocast on an fp32 residual
-stream (what simple_task.py:295 does on the GPU).  Recorded is the MoE half: the tensor entering `norm2` (forward pre-hook, with
+The whole pre-LN transformer layer (rope attention half included) runs on CPU, in fp32 and under the CUDA bf16 autocast policy on an
+fp32 residual stream (what simple_task.py:295 does on the GPU; ref_env.cuda_autocast_bf16).  Recorded is the MoE half: the tensor entering `norm2` (forward pre-hook, with
 its gradient), norm2 / pkm parameters, the layer output and every gradient.  The attention half only hands the MoE half a
 realistic non-leaf input.
 
@@ -78,7 +78,8 @@ def run_case(name, moe_name, bf16, competition=False, B=2, N=48, D=64, E=8, F_=3
                 p.copy_((1.0 if p is layer.norm2.weight else 0.0) + 0.1 * torch.randn(p.shape, generator=g))
         kw = {}
         fx = {"meta": dict(name=name, moe_name=moe_name, bf16=bf16, B=B, N=N, D=D, E=E, F=F_, K=K, competition=competition,
-                           args=vars(args), cvmm="cvmm() replaced by a CPU restatement (Triton needs a GPU)")}
+                           args=vars(args), cvmm=G.ref_env.CVMM_META)}
+        upcasts = {}
         if moe_name == "competesmoe":
             torch.manual_seed(1234)
             layer.pkm.prob_flips_final = {}
@@ -99,14 +100,10 @@ def run_case(name, moe_name, bf16, competition=False, B=2, N=48, D=64, E=8, F_=3
         dy = torch.randn(B, N, D, generator=g)
         xg = x.clone().requires_grad_(True)
         layer.pkm.regularization_present = True
-        G._CVMM_OUT_DTYPE[0] = torch.bfloat16 if bf16 else torch.float32
-        if bf16:
-            with torch.autocast("cpu", dtype=torch.bfloat16):
-                out = layer(xg, None, **kw)
-                reg = layer.pkm.get_reg_loss()
-        else:
+        with G.amp(bf16, upcasts):
             out = layer(xg, None, **kw)
             reg = layer.pkm.get_reg_loss()
+        fx["meta"]["autocast_fp32_upcasts"] = dict(upcasts)
         h.remove()
         loss = (out.float() * dy).sum() + sum(v.float() for v in reg.values())
         loss.backward()
@@ -122,7 +119,6 @@ def run_case(name, moe_name, bf16, competition=False, B=2, N=48, D=64, E=8, F_=3
         fx["eps"] = layer.norm2.eps
     finally:
         os.chdir(cwd)
-        G._CVMM_OUT_DTYPE[0] = torch.float32
     path = os.path.join(HERE, f"pretrain_block_{name}.pt")
     torch.save(fx, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB | out", tuple(out.shape), out.dtype, "mid", mid.dtype,

@@ -33,7 +33,7 @@ def test_argument_validation_without_gpu():
     """Validation runs before any launch, so bad arguments are reported on a CPU-only box too."""
     import pytest
     from competesmoe_amd import _lib
-    rc = _lib.lib.csmoe_router_select(None, 7, 4, 8, 2, 0, 0, None, None, None, None)
+    rc = _lib.lib.csmoe_router_select(None, 7, 4, 8, 2, 0, 0, 1.0, None, None, None, None)
     assert rc == 1 and b"dtype" in _lib.lib.csmoe_last_error()
     with pytest.raises(ValueError):
         _lib.check(rc, "router_select")

@@ -91,14 +91,23 @@ def ref_select(scores, K, mode, round_bf16):
         w = (v / den).to(dt).float()
     elif mode == 2:
         w = torch.softmax(v, -1)
+    elif mode == 4:      # top-k of the logits, sigmoid(v / scale) in the logits' dtype, / fp32 sum rounded to x.dtype
+        sv = torch.sigmoid((v / SIG_SCALE).to(dt).float()).to(dt).float()
+        den = sv.sum(-1, keepdim=True)
+        if round_bf16:
+            den = den.bfloat16().float()
+        w = sv / den
     else:
         den = v.sum(-1, keepdim=True).to(dt).float() + 1e-20
         w = (v / den).to(dt).float()
     return sm, idx, w
 
 
+SIG_SCALE = 2.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("T,E,K", [(1, 4, 1), (77, 8, 2), (512, 64, 2), (300, 63, 7), (256, 128, 8), (64, 300, 4)])
 def test_router_select(T, E, K, mode, dtype):
     g = torch.Generator().manual_seed(E * 7 + K)
@@ -106,11 +115,11 @@ def test_router_select(T, E, K, mode, dtype):
     if mode == 1:
         scores = scores.abs() + 0.1   # affinities are positive (mean softplus)
     scores = scores.to(DEV)
-    sm, idx, w = ops.router_select(scores, K, mode, round_sum_bf16=(dtype == torch.bfloat16))
+    sm, idx, w = ops.router_select(scores, K, mode, round_sum_bf16=(dtype == torch.bfloat16), param=SIG_SCALE)
     rsm, ridx, rw = ref_select(scores.cpu(), K, mode, dtype == torch.bfloat16)
     assert torch.allclose(sm.cpu(), rsm, rtol=2e-6, atol=1e-8)
     # indices bit-exact unless the GPU softmax differs from the CPU one in the last ulp on a near-tie
-    if mode in (1, 2, 3) or dtype == torch.bfloat16:
+    if mode in (1, 2, 3, 4) or dtype == torch.bfloat16:
         assert torch.equal(idx.cpu().long(), ridx)
     else:
         mism = (idx.cpu().long() != ridx).any(-1)
@@ -123,7 +132,7 @@ def test_router_select(T, E, K, mode, dtype):
     assert torch.allclose(w.cpu()[ok], rw[ok], rtol=(1e-5 if dtype == torch.float32 or mode in (0, 2) else 2 ** -7), atol=1e-7)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_router_select_bwd_fp32(mode):
     T, E, K = 200, 16, 3
     g = torch.Generator().manual_seed(5)
@@ -133,8 +142,8 @@ def test_router_select_bwd_fp32(mode):
     dw = torch.randn(T, K, generator=g)
     dsm = torch.randn(T, E, generator=g)
     sd = scores.to(DEV)
-    sm, idx, w = ops.router_select(sd, K, mode, False)
-    ds = ops.router_select_bwd(sd, K, mode, False, sm, idx, w, dw.to(DEV), dsm.to(DEV))
+    sm, idx, w = ops.router_select(sd, K, mode, False, param=SIG_SCALE)
+    ds = ops.router_select_bwd(sd, K, mode, False, sm, idx, w, dw.to(DEV), dsm.to(DEV), param=SIG_SCALE)
     # autograd reference with the SAME indices
     s = scores.clone().requires_grad_(True)
     smr = torch.softmax(s, -1)
@@ -145,6 +154,8 @@ def test_router_select_bwd_fp32(mode):
         v = torch.gather(s, -1, ii); wr = v / v.sum(-1, keepdim=True)
     elif mode == 2:
         wr = torch.softmax(torch.gather(s, -1, ii), -1)
+    elif mode == 4:
+        v = torch.sigmoid(torch.gather(s, -1, ii) / SIG_SCALE); wr = v / v.sum(-1, keepdim=True)
     else:
         v = torch.gather(torch.sigmoid(s), -1, ii); wr = v / (v.sum(-1, keepdim=True) + 1e-20)
     ((wr * dw).sum() + (smr * dsm).sum()).backward()
@@ -356,6 +367,16 @@ def test_colsum_and_softplus(dtype):
     dy = ops.softplus_mean_bwd(y, daff)
     rdy = ((daff.float() / 96).to(dtype).float().unsqueeze(-1) * torch.sigmoid(y.float())).to(dtype)
     assert torch.allclose(dy.float(), rdy.float(), rtol=(1e-5 if dtype == torch.float32 else 2 ** -7), atol=1e-7)
+    if dtype == torch.bfloat16:
+        # CUDA-autocast semantics (pretrain stack): fp32 softplus / mean of the bf16 rows, fp32 affinities, one rounding of dy
+        aff32 = ops.softplus_mean(y, torch.float32)
+        assert aff32.dtype == torch.float32
+        r32 = torch.nn.functional.softplus(y.float()).mean(-1)
+        assert torch.allclose(aff32, r32, rtol=2e-6, atol=1e-7)
+        d32 = torch.randn(300, generator=g).to(DEV)
+        dy32 = ops.softplus_mean_bwd(y, d32)
+        rdy32 = ((d32 / 96).unsqueeze(-1) * torch.sigmoid(y.float())).to(dtype)
+        assert torch.allclose(dy32.float(), rdy32.float(), rtol=2 ** -8, atol=1e-9)
 
 
 def test_argument_errors_raise():

@@ -174,20 +174,22 @@ def test_pretrain_smoe(case, tag):
     o_bias = st["o_bias"].clone().requires_grad_(True) if "o_bias" in st else None
     xx = x.to(op) if meta["bf16"] else x
     lg = O.gate_logits(xx, params["w_gate"].to(xx.dtype))
-    assert rel_l2(lg, fx["gate_logits"]) <= (1e-6 if tag == "fp32" else 1e-2)
+    assert rel_l2(lg, fx["gate_logits"]) <= 1e-6
     w, idx, sm = O.router_topk(lg, meta["K"], x.dtype)
     out = O.pretrain_ffn(x, idx, w, params["keys"], params["values"], "relu", op, bias=bias, o_bias=o_bias)
     reg = O.entropy_balance(lg) * meta["args"]["balance_loss_coef"]
-    r = 1e-5 if tag == "fp32" else 4e-3
+    # the fixtures come from the reference's own Triton kernels and CVMM autograd function; the restatement keeps their rounding
+    # points, so bf16 agrees to a few last-place differences of the fp32 accumulation order (<= 1e-4), not just to bf16 noise
+    r = 1e-5 if tag == "fp32" else 1e-4
     assert rel_l2(out, fx["output"]) <= r, rel_l2(out, fx["output"])
-    assert abs(float(reg) - float(fx["reg_loss"]["mlp_ebalance"])) <= 1e-5
+    assert abs(float(reg) - float(fx["reg_loss"]["mlp_ebalance"])) <= 1e-6
     ((out.float() * fx["dy"]).sum() + reg.float()).backward()
-    assert rel_l2(x.grad, fx["x_grad"]) <= 4 * r
+    assert rel_l2(x.grad, fx["x_grad"]) <= r
     for k, p in params.items():
-        assert rel_l2(p.grad, fx["grads"][k]) <= 4 * r, k
+        assert rel_l2(p.grad, fx["grads"][k]) <= r, k
     if bias is not None:
-        assert rel_l2(bias.grad, fx["grads"]["bias"]) <= 4 * r
-        assert rel_l2(o_bias.grad, fx["grads"]["o_bias"]) <= 4 * r
+        assert rel_l2(bias.grad, fx["grads"]["bias"]) <= r
+        assert rel_l2(o_bias.grad, fx["grads"]["o_bias"]) <= r
 
 
 @pytest.mark.parametrize("tag", TAGS)
@@ -198,41 +200,43 @@ def test_pretrain_competition(tag):
     x = fx["x"].clone().requires_grad_(True)
     keys, values, wg = (st[k].clone().requires_grad_(True) for k in ("keys", "values", "w_gate"))
 
-    def run():
-        xx = x.to(op) if meta["bf16"] else x
-        lg = O.gate_logits(xx, wg.to(xx.dtype))
-        gsm = torch.softmax(lg, -1, dtype=torch.float32)
-        kk, vv = (keys.to(op), values.to(op)) if meta["bf16"] else (keys, values)
-        aw, aidx, asm, aff, topk_out = O.pretrain_dense_affinity(xx, kk, vv, "relu", meta["K"], x.dtype)
-        # affinity scores must match the reference's; indices exact except (near-)ties of bf16 affinities
-        assert rel_l2(aff, fx["aff_scores"]) <= (1e-5 if tag == "fp32" else 4e-3)
-        gi = fx["aff_selected"]
-        mism = (aidx != gi).any(-1)
-        if tag == "fp32":
-            assert int(mism.sum()) == 0
-        else:
-            a = torch.gather(fx["aff_scores"].float(), -1, aidx)[mism]
-            b = torch.gather(fx["aff_scores"].float(), -1, gi)[mism]
-            assert (a.sort(-1).values - b.sort(-1).values).abs().max() <= 2 ** -7 * b.abs().max() if mism.any() else True
-        aw = torch.gather(aff, -1, gi)
-        aw = aw / torch.sum(aw, dim=-1, keepdim=True).to(x.dtype)
-        B, N, _ = x.shape
-        eo = torch.matmul(O.ACTS["relu"](torch.matmul(xx.view(-1, xx.shape[-1]), kk)), vv).transpose(1, 0)
+    opd = op if meta["bf16"] else None
+    xx = x.to(op) if meta["bf16"] else x
+    lg = O.gate_logits(xx, wg.to(xx.dtype))
+    gsm = torch.softmax(lg, -1, dtype=torch.float32)
+    aw, aidx, asm, aff, topk_out = O.pretrain_dense_affinity(x, keys, values, "relu", meta["K"], x.dtype, op_dtype=opd)
+    # under CUDA autocast the affinities are fp32 (softplus is an fp32-policy op): scores and indices must match the reference's
+    assert aff.dtype == fx["aff_scores"].dtype == torch.float32
+    assert rel_l2(aff, fx["aff_scores"]) <= (1e-5 if tag == "fp32" else 2e-4), rel_l2(aff, fx["aff_scores"])
+    gi = fx["aff_selected"]
+    mism = (aidx != gi).any(-1)
+    if tag == "fp32":
+        assert int(mism.sum()) == 0
+    elif mism.any():       # fp32 scores from bf16 GEMM outputs whose accumulation order differs: near-ties only
+        a = torch.gather(fx["aff_scores"], -1, aidx)[mism]
+        b = torch.gather(fx["aff_scores"], -1, gi)[mism]
+        assert float(mism.float().mean()) <= 0.02
+        assert (a.sort(-1).values - b.sort(-1).values).abs().max() <= 2e-4 * b.abs().max()
+    assert torch.allclose(torch.gather(aff, -1, gi) / torch.gather(aff, -1, gi).sum(-1, keepdim=True), fx["aff_weights"],
+                          rtol=(1e-5 if tag == "fp32" else 2e-3), atol=1e-6)
+    aw = torch.gather(aff, -1, gi)
+    aw = aw / torch.sum(aw, dim=-1, keepdim=True).to(x.dtype)
+    B, N, _ = x.shape
+    topk_out = O.pretrain_dense_affinity(x, keys, values, "relu", meta["K"], x.dtype, op_dtype=opd)[4] if not mism.any() else None
+    if topk_out is None:
+        kk, vv = keys.to(op), values.to(op)
+        eo = torch.matmul(O.ACTS["relu"](torch.matmul(xx.reshape(-1, xx.shape[-1]), kk)), vv).transpose(1, 0)
         eo = eo.reshape(B, N, *eo.shape[1:])
         topk_out = torch.gather(eo, 2, gi.unsqueeze(-1).expand(B, N, meta["K"], eo.size(-1)))
-        out = O.pretrain_ffn(x, gi, aw, keys, values, "relu", op)
-        div = O.experts_diversity_loss(topk_out) * a_["balance_loss_coef_comp"] / 2
-        rl = O.router_loss(gsm, asm.detach()) * a_["router_loss_coef"]
-        return out, div, rl
-    if meta["bf16"]:
-        with torch.autocast("cpu", dtype=torch.bfloat16):
-            out, div, rl = run()
-    else:
-        out, div, rl = run()
-    r = 1e-5 if tag == "fp32" else 6e-3
+    out = O.pretrain_ffn(x, gi, aw, keys, values, "relu", op)
+    div = O.pretrain_diversity_loss(topk_out, opd) * a_["balance_loss_coef_comp"] / 2
+    rl = O.router_loss(gsm, asm.detach()) * a_["router_loss_coef"]
+    r = 1e-5 if tag == "fp32" else 4e-3
+    print("pretrain_competition", tag, "out", rel_l2(out, fx["output"]), "div", float(div), float(fx["reg_loss"]["mlp_comp_diver_loss"]),
+          "rl", float(rl), float(fx["reg_loss"]["mlp_router_loss"]), "mism", int(mism.sum()))
     assert rel_l2(out, fx["output"]) <= r, rel_l2(out, fx["output"])
-    assert abs(float(div) - float(fx["reg_loss"]["mlp_comp_diver_loss"])) <= (1e-7 if tag == "fp32" else 2e-5)
-    assert abs(float(rl) - float(fx["reg_loss"]["mlp_router_loss"])) <= (1e-7 if tag == "fp32" else 2e-5)
+    assert abs(float(div) - float(fx["reg_loss"]["mlp_comp_diver_loss"])) <= (1e-7 if tag == "fp32" else 2e-6)
+    assert abs(float(rl) - float(fx["reg_loss"]["mlp_router_loss"])) <= (1e-7 if tag == "fp32" else 1e-6)
 
 
 @pytest.mark.parametrize("tag", TAGS)
@@ -254,12 +258,19 @@ def test_pretrain_deepseek(mode, tag):
         for k, p in ps.items():
             assert rel_l2(p.grad, fx["grads"][k]) <= 4e-5, k
     else:
-        # bf16 logits have near-ties: rows routed differently from the CPU-autocast reference are rare outliers
+        # bf16 logits / sigmoids have exact ties: torch.topk's choice among equal values is unspecified, the restatement takes the
+        # lowest index.  Such rows are rare outliers; every other row agrees to accumulation-order noise.
         o2, g2 = out.detach().reshape(-1, out.shape[-1]).double(), fx["output"].reshape(-1, out.shape[-1]).double()
         row_err = (o2 - g2).norm(dim=-1) / (g2.norm(dim=-1) + 1e-12)
         bad = row_err > 5e-2
-        assert bad.float().mean() <= 0.05
-        assert rel_l2(o2[~bad], g2[~bad]) <= 8e-3
+        assert bad.float().mean() <= 0.01
+        assert rel_l2(o2[~bad], g2[~bad]) <= 1e-4
+        assert abs(float(reg) - float(fx["reg_loss"]["mlp_ebalance"])) <= 1e-6
+        if not bool(bad.any()):
+            ((out.float() * fx["dy"]).sum() + reg.float()).backward()
+            assert rel_l2(x.grad, fx["x_grad"]) <= 2e-4
+            for k, p in ps.items():
+                assert rel_l2(p.grad, fx["grads"][k]) <= (1e-3 if k == "w_gate" else 1e-4), k
 
 
 @pytest.mark.parametrize("case", ["competesmoe_cosine", "competesmoe_normweight", "competesmoe_normsigmoid"])
