@@ -186,6 +186,9 @@ class EPFFN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.saved is None:
+            raise RuntimeError("competesmoe_amd: saved activations were freed by the first backward pass; a second backward "
+                               "through the same graph (retain_graph=True) is not supported -- run the forward again")
         bins, lb, plan, rs, hpre, hact, y = ctx.saved
         ctx.saved = None
         tab, group = ctx.tab, ctx.group
@@ -271,6 +274,9 @@ class EPFFNChunked(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.saved is None:
+            raise RuntimeError("competesmoe_amd: saved activations were freed by the first backward pass; a second backward "
+                               "through the same graph (retain_graph=True) is not supported -- run the forward again")
         bins, plan, cps, saved, y = ctx.saved
         ctx.saved = None
         tab, group = ctx.tab, ctx.group
@@ -337,6 +343,19 @@ class EPFFNChunked(torch.autograd.Function):
         return (dx2, dw, None, None, None, None, None, None, *pg)
 
 
+def reduce_grad_on_backward(param: torch.Tensor, group=None):
+    """Sum the gradient of a REPLICATED parameter over the expert-parallel group, once per backward pass, BEFORE it is
+    accumulated into `param.grad`: with gradient accumulation (several micro-batches per optimizer step -- the pretrain loop,
+    simple_task.py:286-320, and LLaVA's gradient_accumulation_steps) `param.grad` ends up as sum_r sum_mb g.  A
+    post-accumulate hook that reduces `param.grad` itself would re-reduce the earlier micro-batches' sum on every pass."""
+    def hook(g):
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            g = g.clone()
+            dist.all_reduce(g, group=group)
+        return g
+    return param.register_hook(hook)
+
+
 # ------------------------------------------------------------------------------------------------ module
 @register_moe("smoe_ep")
 class EPSMoeLayer(MoeLayer):
@@ -352,11 +371,7 @@ class EPSMoeLayer(MoeLayer):
         self.group = group
         self.chunks = chunks        # groups of local experts whose exchanges overlap the GEMMs; None: CSMOE_EP_CHUNKS, else 2 (1 at P=1)
         self.init_gate_weights()
-        self.gate.weight.register_post_accumulate_grad_hook(self._sync_gate_grad)
-
-    def _sync_gate_grad(self, p):
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(p.grad, group=self.group)
+        reduce_grad_on_backward(self.gate.weight, group)
 
     def _n_chunks(self) -> int:
         c = self.chunks

@@ -246,7 +246,9 @@ class ExpertTable:
 
 
 # Operand-dtype copies of fp32 master weights kept across calls while the parameter is unchanged (same storage, same autograd
-# version counter: every in-place update through torch bumps it).  The reference's pretrain task runs several micro-batches per
+# version counter).  In-place updates through the parameter itself (optimizer.step(), p.mul_()) bump that counter; writes through
+# `p.data` / `p.detach()` (DeepSpeed / apex bf16 optimizers, EMA, weight clipping) do NOT -- `.data` carries its own counter -- so
+# with such a writer call `invalidate_weight_cache()` after every update (e.g. from an optimizer-step post hook).  The reference's pretrain task runs several micro-batches per
 # optimizer step (simple_task.py:286-320) and evaluates between steps: all but the first forward after an update then skip the
 # HBM-bound cast (34.5 GB at the headline shape).  Opt-in -- CSMOE_WEIGHT_CACHE=1 or `weight_cache(True)` -- because it holds one
 # bf16 copy of the expert weights per layer for as long as the layer lives, and because a writer that goes around torch (a raw
@@ -260,6 +262,11 @@ def weight_cache(enabled: bool) -> None:
     _WEIGHT_CACHE_ON = bool(enabled)
     if not enabled:
         _WEIGHT_CACHE.clear()
+
+
+def invalidate_weight_cache() -> None:
+    """Drop every cached operand copy (for writers that bypass the autograd version counter, see above)."""
+    _WEIGHT_CACHE.clear()
 
 
 def _cached_copy(t: torch.Tensor, op):
@@ -330,6 +337,10 @@ def _grouped_wgrad(a: torch.Tensor, b: torch.Tensor, bins, E: int, pd) -> torch.
 
 def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool):
     """Returns dx2, dw, (gW1 [E,..], gb1 [E,F]|None, gW2 [E,..], gb2 [E,Dout]|None)."""
+    if saved is None:
+        raise RuntimeError("competesmoe_amd: the MoE layer's saved activations were freed by the first backward pass "
+                           "(they are released early to bound memory); a second backward through the same graph "
+                           "(retain_graph=True) is not supported -- run the forward again")
     bins, xs, hpre, hact, y = saved
     T = dout.shape[0]
     dev = dout.device
@@ -521,7 +532,7 @@ class DenseFFN(torch.autograd.Function):
                 return None
             if t.dtype == op:
                 return t.contiguous()
-            if _WEIGHT_CACHE_ON:
+            if _WEIGHT_CACHE_ON and t._base is None:      # fresh slices (keys[e]) die with the call: their entries could never hit
                 c, hit = _cached_copy(t, op)
                 if not hit:
                     c = t.to(op)

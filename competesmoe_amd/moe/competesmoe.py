@@ -6,6 +6,7 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from ..functional import RouterSelect, SoftplusMean
+from ..schedule import draw_balanced_flips
 from .register import register_moe
 from .moe import MoeLayer
 
@@ -28,6 +29,7 @@ class CompeteSMoE(MoeLayer):
         self.is_prob_flips = True
         self.register_buffer("prob_flips", torch.zeros(15801))   # same placeholder shape as competesmoe.py:32
         self._flips_host = None
+        self._flips_key = None
         self.init_gate_weights()
 
     # ------------------------------------------------------------------ schedule (competesmoe.py:35-179)
@@ -44,32 +46,7 @@ class CompeteSMoE(MoeLayer):
         device = self.gate.weight.device
         cap = self.args.max_compete_in_iter
         if rank == 0:
-            # host-side restatement of create_balanced_flip_current (:86-130): one torch.rand(1) per slot on the SAME
-            # device RNG stream the reference uses (cuda if available else cpu), left-then-right shifting at the cap
-            rng_dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-            freq = [0] * flip_steps
-            for v in prob_flips_final.values():
-                for i, b in enumerate(v.tolist()):
-                    freq[i] += int(b)
-            cur = [False] * flip_steps
-            for i in range(flip_steps):
-                if torch.rand(1, device=rng_dev).item() < self.rate_flip:
-                    if freq[i] < cap:
-                        cur[i] = True
-                        freq[i] += 1
-                    else:
-                        found = False
-                        for j in range(i - 1, -1, -1):
-                            if freq[j] < cap and not cur[j]:
-                                cur[j], found = True, True
-                                freq[j] += 1
-                                break
-                        if not found:
-                            for j in range(i + 1, flip_steps):
-                                if freq[j] < cap and not cur[j]:
-                                    cur[j] = True
-                                    freq[j] += 1
-                                    break
+            cur = draw_balanced_flips(flip_steps, self.rate_flip, cap, prob_flips_final)
             probs_current = torch.tensor(cur, dtype=torch.bool, device=device)
         else:
             probs_current = torch.empty(flip_steps, dtype=torch.bool, device=device)
@@ -77,7 +54,7 @@ class CompeteSMoE(MoeLayer):
             dist.broadcast(probs_current, src=0)
         prob_flips_final[id_layer] = probs_current
         self.prob_flips = probs_current
-        self._flips_host = probs_current.tolist()     # one host copy: the per-step branch test needs no device sync
+        self._flips_host = None                        # host copy (no per-step device sync); rebuilt by _competing
         self.is_prob_flips = False
         return prob_flips_final
 
@@ -89,8 +66,10 @@ class CompeteSMoE(MoeLayer):
         if not x.requires_grad or self.step_warm is None or self.current_steps < self.step_warm:
             return False
         i = self.current_steps - self.step_warm
-        if self._flips_host is None or len(self._flips_host) != self.prob_flips.numel():
-            self._flips_host = self.prob_flips.tolist()       # buffer replaced (e.g. load_state_dict): refresh once
+        t = self.prob_flips
+        key = (t.data_ptr(), t._version, t.numel())           # load_state_dict copies IN PLACE: the version counter moves
+        if self._flips_host is None or self._flips_key != key:
+            self._flips_host, self._flips_key = t.tolist(), key
         return bool(self._flips_host[i] == 1)
 
     # ------------------------------------------------------------------ policies

@@ -7,6 +7,7 @@ import torch.nn.functional as F
 from .. import _lib as L
 from ..functional import DenseFFN, DiversityLoss, RouterSelect, SoftplusMean
 from .moe import MoE, op_dtype
+from ..schedule import draw_balanced_flips
 from .register import register_moe
 
 
@@ -38,30 +39,7 @@ class CompeteSMoE(MoE):
         device = self.w_gate.device
         cap = self.max_compete_in_iter
         if rank == 0:
-            rng_dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-            freq = [0] * flip_steps
-            for v in self.prob_flips_final.values():
-                for i, b in enumerate(v.tolist()):
-                    freq[i] += int(b)
-            cur = [False] * flip_steps
-            for i in range(flip_steps):
-                if torch.rand(1, device=rng_dev).item() < self.rate_flip:
-                    if freq[i] < cap:
-                        cur[i] = True
-                        freq[i] += 1
-                    else:
-                        found = False
-                        for j in range(i - 1, -1, -1):
-                            if freq[j] < cap and not cur[j]:
-                                cur[j], found = True, True
-                                freq[j] += 1
-                                break
-                        if not found:
-                            for j in range(i + 1, flip_steps):
-                                if freq[j] < cap and not cur[j]:
-                                    cur[j] = True
-                                    freq[j] += 1
-                                    break
+            cur = draw_balanced_flips(flip_steps, self.rate_flip, cap, self.prob_flips_final)
             probs_current = torch.tensor(cur, dtype=torch.bool, device=device)
         else:
             probs_current = torch.empty(flip_steps, dtype=torch.bool, device=device)
@@ -79,10 +57,11 @@ class CompeteSMoE(MoE):
         if not x.requires_grad or self.step_warm is None or self.current_steps < self.step_warm:
             return False
         t = self.prob_flips_final[id_layer]
+        key = (t.data_ptr(), t._version, t.numel())       # a checkpoint load / in-place edit of the schedule refreshes the host copy
         h = self._flips_host.get(id_layer)
-        if h is None or len(h) != t.numel():
-            h = self._flips_host[id_layer] = t.tolist()
-        return bool(h[self.current_steps - self.step_warm] == 1)
+        if h is None or h[0] != key:
+            h = self._flips_host[id_layer] = (key, t.tolist())
+        return bool(h[1][self.current_steps - self.step_warm] == 1)
 
     # ------------------------------------------------------------------ policies
     _fuses_residual = True

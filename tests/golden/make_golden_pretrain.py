@@ -127,6 +127,38 @@ def cvmm_index_case():
     print("wrote pretrain_cvmm_sel.pt")
 
 
+def cvmm_kernel_case(bf16):
+    """The reference's `cvmm()` itself (both Triton kernels + the CVMM autograd function) on random operands with the two-call
+    protocol of the MoE layers (smoe.py:237-248): scores = relu(cvmm(x, sel, keys)); out = cvmm(scores, sel', values) with
+    reduction weights.  Outputs and the gradients of x, keys, values, w."""
+    _import_reference()
+    cv = sys.modules["layers.cvmm"]
+    T, K, E, D, Fh = 300, 2, 8, 32, 48
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, T // 2, D, generator=g).requires_grad_(True)
+    keys = (torch.randn(E, D, Fh, generator=g) / 6).requires_grad_(True)
+    values = (torch.randn(E, Fh, D, generator=g) / 6).requires_grad_(True)
+    idx = torch.rand(2, T // 2, E, generator=g).topk(K, -1).indices
+    w = torch.rand(2, T // 2, K, generator=g).requires_grad_(True)
+    dy = torch.randn(2, T // 2, D, generator=g)
+    with amp(bf16, {}):
+        sel = cv.cvmm_prepare_sel2(idx.int())
+        scores = torch.relu(cv.cvmm(x, sel, keys))
+        sel2 = sel.clone()
+        sel2.reduction_weight = w
+        sel2.sel_index = sel2.out_index
+        sel2.out_index = None
+        out = cv.cvmm(scores, sel2, values)
+    (out.float() * dy).sum().backward()
+    fx = {"meta": dict(bf16=bf16, T=T, K=K, E=E, D=D, F=Fh, cvmm=ref_env.CVMM_META),
+          "x": x.detach().clone(), "keys": keys.detach().clone(), "values": values.detach().clone(), "idx": idx.clone(),
+          "w": w.detach().clone(), "dy": dy, "scores": scores.detach().clone(), "output": out.detach().clone(),
+          "grads": {"x": x.grad.clone(), "keys": keys.grad.clone(), "values": values.grad.clone(), "w": w.grad.clone()}}
+    tag = "bf16" if bf16 else "fp32"
+    torch.save(fx, os.path.join(HERE, f"pretrain_cvmm_kernels_{tag}.pt"))
+    print(f"wrote pretrain_cvmm_kernels_{tag}.pt", out.dtype, scores.dtype)
+
+
 def schedule_case():
     get_moe = _import_reference()
     args = make_args(moe_name="competesmoe", stop_after=40, warm_up=0.25, rate_flip=0.6, max_compete_in_iter=2)
@@ -168,6 +200,8 @@ def main():
     # BASELINE config 1: D=256, E=8, K=2, F=128, T=1024 as [4,256] -- checksums only
     run_case("config1_smoe_fp32", "smoe", False, B=4, N=256, D=256, E=8, F_=128, K=2, full=False)
     cvmm_index_case()
+    cvmm_kernel_case(False)
+    cvmm_kernel_case(True)
     schedule_case()
 
 

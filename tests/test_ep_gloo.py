@@ -87,3 +87,39 @@ def test_ep_exchange_two_ranks_gloo(T, D, E, K):
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from competesmoe_amd import ep
+        w = torch.nn.Parameter(torch.arange(12, dtype=torch.float32).view(3, 4) / 10)
+        ep.reduce_grad_on_backward(w, None)
+        xs = [torch.randn(5, 4, generator=torch.Generator().manual_seed(10 * mb + r)) for r in range(world) for mb in range(2)]
+        mine = [xs[rank * 2 + mb] for mb in range(2)]
+        for x in mine:                                   # two micro-batches accumulate into w.grad
+            (x @ w.t()).square().sum().backward()
+        # expectation: ONE backward over every rank's and micro-batch's rows
+        w2 = w.detach().clone().requires_grad_(True)
+        (torch.cat(xs) @ w2.t()).square().sum().backward()
+        q.put((rank, bool(torch.allclose(w.grad, w2.grad, rtol=1e-5, atol=1e-6))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicated_gate_gradient_with_two_micro_batches_gloo():
+    """the gate gradient of the expert-parallel layer is reduced per backward pass, so gradient accumulation over
+    micro-batches gives sum_r sum_mb g and not P * (earlier sums) + ..."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res == {0: True, 1: True}

@@ -325,3 +325,23 @@ def test_pretrain_router_loss_variants(case):
     assert abs(float(rl * a_["router_loss_coef"]) - float(fx["reg_loss"]["mlp_router_loss"])) <= 1e-7
     out = O.pretrain_ffn(x, aidx, aw, keys, values, "relu", torch.float32)
     assert rel_l2(out, fx["output"]) <= 1e-5
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_cvmm_restatement_against_the_reference_kernels(tag):
+    """oracle.cvmm_ref (forward and CVMM.backward's rounding points) against the reference's own `cvmm()` run by the Triton
+    interpreter on random operands, two-call protocol (tests/golden/make_golden_pretrain.py::cvmm_kernel_case)."""
+    fx = load(f"pretrain_cvmm_kernels_{tag}")
+    op = torch.bfloat16 if fx["meta"]["bf16"] else torch.float32
+    K, E = fx["meta"]["K"], fx["meta"]["E"]
+    x, keys, values, w = (fx[k].clone().requires_grad_(True) for k in ("x", "keys", "values", "w"))
+    idx = fx["idx"]
+    _, _, perm = O.bin_tokens(idx, E)
+    ssel = idx.flatten()[perm]
+    scores = torch.relu(O.cvmm_ref(x, ssel, perm // K, perm, keys, op).view(*idx.shape, -1))
+    out = O.cvmm_ref(scores, ssel, perm, None, values, op, reduction_weight=w)
+    r = 1e-5 if tag == "fp32" else 1e-4
+    assert rel_l2(scores, fx["scores"]) <= r and rel_l2(out, fx["output"]) <= r
+    (out.float() * fx["dy"]).sum().backward()
+    for name, t in (("x", x), ("keys", keys), ("values", values), ("w", w)):
+        assert rel_l2(t.grad, fx["grads"][name]) <= r, (name, rel_l2(t.grad, fx["grads"][name]))

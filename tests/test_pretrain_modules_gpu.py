@@ -1,8 +1,13 @@
-"""GPU parity of the pretrain-stack layers (HIP path) against golden vectors captured from the reference classes
-(cvmm arithmetic of the goldens = CPU restatement, see tests/golden/make_golden_pretrain.py).
+"""GPU parity of the pretrain-stack layers (HIP path) against golden vectors captured from the reference classes RUNNING THE
+REFERENCE'S OWN TRITON KERNELS (cvmm_kernel / cvmm_backward_kernel3 under the Triton interpreter) and, for bf16, under the CUDA
+autocast policy the reference trains with (tests/golden/make_golden_pretrain.py, tests/golden/ref_env.py).
 
-fp32 <= 1e-5 (max err / max|ref|); bf16-autocast <= 4e-3 relative L2 (the goldens' bf16 path ran under CPU autocast whose
-op list differs slightly from the GPU's; kernel-level bf16 rounding parity is covered by tests/test_ops_gpu.py)."""
+Tolerances (observed values: profiles/r02/parity_report.txt): fp32 <= 1e-5 (max err / max|ref|), gradients <= 4e-5 relative L2.
+bf16 autocast: rows routed like the reference <= BF16_OUT relative L2; rows routed differently (exact ties of bf16 logits /
+sigmoids, where torch.topk's choice is unspecified and the kernel takes the lowest index) <= BF16_BAD_ROWS of the fixture;
+gradients <= BF16_GRAD (the HIP backward scales the upstream gradient by the weight BEFORE the dH GEMM, cvmm.py:538-547 scales
+the rounded product after it: one bf16 rounding apart).  Competition steps route on fp32 affinities like the reference, so the
+same bounds hold for them."""
 import types
 
 import pytest
@@ -18,6 +23,7 @@ if torch.cuda.is_available():
     from competesmoe_amd.pretrain import get_moe, cvmm, cvmm_prepare_sel2
 
 CASES = ["smoe", "smoe_bias", "competesmoe_router", "competesmoe_comp", "competesmoe_comp_hybrid", "deepseekv2", "deepseekv3"]
+BF16_OUT, BF16_BAD_ROWS, BF16_GRAD = 2e-3, 0.03, 2e-2        # provisional: calibrated from tools/parity_report.py
 
 
 def build(fx):
@@ -55,22 +61,28 @@ def test_pretrain_layer_matches_golden(case, tag):
     assert out.dtype == fx["output"].dtype      # bf16 under autocast, except fp32 when the fp32 o_bias is added (as upstream)
     assert set(reg) == set(fx["reg_loss"])
     comp = fx["meta"]["competition"]
-    tol = 1e-5 if not bf16 else (4e-3 if not comp else 0.2)   # bf16 competition: near-tie routing (see llava test)
     gold = fx["output"].to(DEV)
     routed_same = True
     if not bf16:
-        assert max_rel(out, gold) <= tol, max_rel(out, gold)
+        assert max_rel(out, gold) <= 1e-5, max_rel(out, gold)
     else:
-        # bf16 logits / affinities have near-ties: a token whose top-k differs from the reference's shows up as ONE row with
-        # an O(1) error.  Such rows must be rare; every other row must be within tolerance.
         o2, g2 = out.detach().reshape(-1, out.shape[-1]).double(), gold.reshape(-1, out.shape[-1]).double()
         row_err = (o2 - g2).norm(dim=-1) / (g2.norm(dim=-1) + 1e-12)
         bad = row_err > 5e-2
         routed_same = not bool(bad.any())
-        assert bad.float().mean() <= (0.03 if not comp else 0.12), bad.float().mean()
-        assert rel_l2(o2[~bad], g2[~bad]) <= 6e-3, rel_l2(o2[~bad], g2[~bad])
+        assert bad.float().mean() <= BF16_BAD_ROWS, bad.float().mean()
+        assert rel_l2(o2[~bad], g2[~bad]) <= BF16_OUT, rel_l2(o2[~bad], g2[~bad])
+    if comp:
+        # the competition routes on the affinities: fp32 under autocast (softplus is an fp32-policy op), so the selected sets agree
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            aw, aidx, asm, aff, _ = layer.competition_policy_mlp_faster(fx["x"].to(DEV))
+        assert aff.dtype == torch.float32 == fx["aff_scores"].dtype
+        assert rel_l2(aff.cpu(), fx["aff_scores"]) <= (1e-5 if not bf16 else 2e-3)
+        mism = (aidx.cpu().long().sort(-1).values != fx["aff_selected"].sort(-1).values).any(-1)
+        assert mism.float().mean() <= (0.0 if not bf16 else BF16_BAD_ROWS), mism.float().mean()
+    slack = 0.0 if routed_same else 1.0
     for k, v in fx["reg_loss"].items():
-        assert abs(float(reg[k]) - float(v)) <= (2e-6 if not bf16 else (2e-4 if not comp else 2e-3)) + 1e-4 * abs(float(v)), k
+        assert abs(float(reg[k]) - float(v)) <= (2e-6 if not bf16 else 2e-5 * (1 + 20 * slack)) + 1e-4 * abs(float(v)), k
     loss = (out.float() * dy).sum() + sum(v.float() for v in reg.values())
     loss.backward()
     if not bf16:
@@ -81,10 +93,12 @@ def test_pretrain_layer_matches_golden(case, tag):
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
                 continue
             assert rel_l2(p.grad, g.to(DEV)) <= 4e-5, (name, rel_l2(p.grad, g.to(DEV)))
-    elif not comp and routed_same:
-        assert rel_l2(x.grad, fx["x_grad"].to(DEV)) <= 2e-2
-        for name in ("keys", "values", "w_gate"):
-            assert rel_l2(getattr(layer, name).grad, fx["grads"][name].to(DEV)) <= 2e-2, name
+    elif routed_same:
+        assert rel_l2(x.grad, fx["x_grad"].to(DEV)) <= BF16_GRAD, rel_l2(x.grad, fx["x_grad"].to(DEV))
+        for name, p in layer.named_parameters():
+            g = fx["grads"].get(name)
+            if g is not None and p.grad is not None:
+                assert rel_l2(p.grad, g.to(DEV)) <= BF16_GRAD, (name, rel_l2(p.grad, g.to(DEV)))
 
 
 @pytest.mark.parametrize("case", ["competesmoe_cosine", "competesmoe_normweight", "competesmoe_normsigmoid", "competesmoe_comp_intopk",
@@ -114,34 +128,39 @@ def test_config1_checksums():
         assert abs(float(getattr(layer, name).grad.double().norm()) - float(n)) <= 2e-5 * float(n), name
 
 
-def test_cvmm_api_matches_reference_semantics():
-    """cvmm(x, sel, keys) / cvmm_prepare_sel2 with the reference's two-call protocol (smoe.py:237-248)."""
-    T, K, E, D, Fh = 300, 2, 8, 32, 48
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, T // 2, D, generator=g).to(DEV).requires_grad_(True)
-    keys = (torch.randn(E, D, Fh, generator=g) / 6).to(DEV).requires_grad_(True)
-    values = (torch.randn(E, Fh, D, generator=g) / 6).to(DEV).requires_grad_(True)
-    idx = torch.rand(2, T // 2, E, generator=g).topk(K, -1).indices.to(DEV)
-    w = torch.rand(2, T // 2, K, generator=g).to(DEV).requires_grad_(True)
-    sel = cvmm_prepare_sel2(idx.int(), n_experts=E)
-    fx = load("pretrain_cvmm_sel")
-    s2 = cvmm_prepare_sel2(fx["sel"].to(DEV), n_experts=8)
-    assert torch.equal(s2.sel.cpu().flatten().int(), fx["sorted"].flatten())          # same sorted expert ids as the reference
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_cvmm_api_matches_the_reference_kernels(tag):
+    """cvmm(x, sel, keys) / cvmm_prepare_sel2 with the reference's two-call protocol (smoe.py:237-248) against the outputs and
+    gradients of the reference's own `cvmm()` -- cvmm_kernel, cvmm_backward_kernel3 and CVMM.backward run by the Triton interpreter
+    (tests/golden/make_golden_pretrain.py::cvmm_kernel_case)."""
+    fx = load(f"pretrain_cvmm_kernels_{tag}")
+    bf16 = fx["meta"]["bf16"]
+    E = fx["meta"]["E"]
+    x = fx["x"].to(DEV).requires_grad_(True)
+    keys = fx["keys"].to(DEV).requires_grad_(True)
+    values = fx["values"].to(DEV).requires_grad_(True)
+    w = fx["w"].to(DEV).requires_grad_(True)
+    idx = fx["idx"].to(DEV)
+    sx = load("pretrain_cvmm_sel")
+    s2 = cvmm_prepare_sel2(sx["sel"].to(DEV), n_experts=8)
+    assert torch.equal(s2.sel.cpu().flatten().int(), sx["sorted"].flatten())          # same sorted expert ids as the reference
     assert torch.equal(s2.sel_index.cpu().long(), (s2.out_index.cpu() // 2).long())
-    scores = torch.relu(cvmm(x, sel, keys))                       # [2, T/2, K, Fh]
-    sel2 = sel.clone()
-    sel2.reduction_weight = w
-    sel2.sel_index = sel2.out_index
-    sel2.out_index = None
-    out = cvmm(scores, sel2, values)                              # [2, T/2, D]
-    # dense reference
-    h = torch.relu(torch.einsum("btd,btkdf->btkf", x, keys[idx]))
-    ref = torch.einsum("btk,btkf,btkfd->btd", w, h, values[idx])
-    assert max_rel(out, ref) <= 2e-5
-    gr = torch.autograd.grad(ref.sum(), [x, keys, values, w])
-    go = torch.autograd.grad(out.sum(), [x, keys, values, w])
-    for a, b in zip(go, gr):
-        assert max_rel(a, b) <= 5e-5
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        sel = cvmm_prepare_sel2(idx.int(), n_experts=E)
+        scores = torch.relu(cvmm(x, sel, keys))                       # [2, T/2, K, F]
+        sel2 = sel.clone()
+        sel2.reduction_weight = w
+        sel2.sel_index = sel2.out_index
+        sel2.out_index = None
+        out = cvmm(scores, sel2, values)                              # [2, T/2, D]
+    assert scores.dtype == fx["scores"].dtype and out.dtype == fx["output"].dtype
+    tol = 1e-5 if not bf16 else 2e-3
+    assert rel_l2(scores, fx["scores"].to(DEV)) <= tol, rel_l2(scores, fx["scores"].to(DEV))
+    assert rel_l2(out, fx["output"].to(DEV)) <= tol, rel_l2(out, fx["output"].to(DEV))
+    (out.float() * fx["dy"].to(DEV)).sum().backward()
+    gt = 4e-5 if not bf16 else 1.5e-2
+    for name, t in (("x", x), ("keys", keys), ("values", values), ("w", w)):
+        assert rel_l2(t.grad, fx["grads"][name].to(DEV)) <= gt, (name, rel_l2(t.grad, fx["grads"][name].to(DEV)))
 
 
 def test_relu_pass_rate_is_logged_every_log_interval():
