@@ -220,13 +220,13 @@ int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, in
   CSMOE_CHECK_ARG(dtype_ok(dtype), "grouped_gemm: bad dtype %d", dtype);
   CSMOE_CHECK_ARG(E > 0 && M >= 0 && N > 0 && Kd > 0, "grouped_gemm: bad shape E=%d M=%d N=%d Kd=%d", E, M, N, Kd);
   CSMOE_CHECK_ARG(b_layout == CSMOE_B_NK || b_layout == CSMOE_B_KN, "grouped_gemm: bad B layout %d", b_layout);
-  CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && act >= 0 && act <= 5, "grouped_gemm: bad epilogue/act");
-  CSMOE_CHECK_ARG(b_ptrs && offsets && (M == 0 || (A && C)), "grouped_gemm: null pointer");
+  CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 4 && act >= 0 && act <= 5, "grouped_gemm: bad epilogue/act");
+  CSMOE_CHECK_ARG(b_ptrs && offsets && (M == 0 || (A && (C || ((epilogue == CSMOE_EPI_BIAS_ACT || epilogue == CSMOE_EPI_ROUND_BIAS32_ACT) && C2)))), "grouped_gemm: null pointer");
   CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "grouped_gemm: ACTGRAD epilogue needs aux");
   CSMOE_CHECK_ARG(lda >= Kd && ldc >= N && ldb >= (b_layout == CSMOE_B_NK ? Kd : N), "grouped_gemm: leading dimension too small");
   if (M == 0) return CSMOE_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C)) {
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C ? C : C2)) {
     if (use_v2_rowspace(M, N, Kd))
       return gg8_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
                           nullptr, nullptr, st);
@@ -241,11 +241,11 @@ int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, in
                      int Kd, void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, int dtype,
                      int force_generic, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && M >= 0 && N > 0 && Kd > 0, "dense_gemm: bad arguments");
-  CSMOE_CHECK_ARG(M == 0 || (A && B && C), "dense_gemm: null pointer");
+  CSMOE_CHECK_ARG(M == 0 || (A && B && (C || ((epilogue == CSMOE_EPI_BIAS_ACT || epilogue == CSMOE_EPI_ROUND_BIAS32_ACT) && C2))), "dense_gemm: null pointer");
   CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "dense_gemm: ACTGRAD epilogue needs aux");
   if (M == 0) return CSMOE_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C)) {
+  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C ? C : C2)) {
     if (use_v2_rowspace(M, N, Kd))
       return gg8_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B,
                           bias, st);

@@ -434,10 +434,15 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   const int er = threadIdx.x >> 5;             // 0..15
   const int ncol = tc0 + ec;
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (MODE == 0 && ncol < p.NC && (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT)) {
-    const bf16* bias = (const bf16*)(p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias);
-    if (bias) {
-      bf16x8 b8 = *(const bf16x8*)(bias + ncol);
+  const bool post_bias = p.epilogue == CSMOE_EPI_ROUND_BIAS32_ACT;     // fp32 bias added to the ROUNDED product (cvmm + bias)
+  if (MODE == 0 && ncol < p.NC && (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias)) {
+    const void* bias = p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias;
+    if (bias && post_bias) {
+      const f32x4 b0 = *(const f32x4*)((const float*)bias + ncol), b1 = *(const f32x4*)((const float*)bias + ncol + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bv[j] = b0[j]; bv[4 + j] = b1[j]; }
+    } else if (bias) {
+      bf16x8 b8 = *(const bf16x8*)((const bf16*)bias + ncol);
 #pragma unroll
       for (int j = 0; j < 8; ++j) bv[j] = (float)b8[j];
     }
@@ -476,9 +481,12 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
             *(bf16x8*)((bf16*)p.C + o) = o0;
           } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { o0[j] = (bf16)(v[j] + bv[j]); v[j] = (float)o0[j]; }
-            *(bf16x8*)((bf16*)p.C + o) = o0;
-            if (p.epilogue == CSMOE_EPI_BIAS_ACT && p.C2) {
+            for (int j = 0; j < 8; ++j) {
+              if (post_bias) { v[j] = (float)(bf16)v[j] + bv[j]; o0[j] = (bf16)v[j]; }      // act sees the fp32 sum
+              else { o0[j] = (bf16)(v[j] + bv[j]); v[j] = (float)o0[j]; }
+            }
+            if (p.C) *(bf16x8*)((bf16*)p.C + o) = o0;          // null: the caller keeps the activated output only (ReLU)
+            if ((p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias) && p.C2) {
               act_fwd8(v, p.act);
               bf16x8 o1;
 #pragma unroll

@@ -105,9 +105,10 @@ __global__ void __launch_bounds__(256) gg_generic_kernel(GGArgs p) {
   if (MODE == 0) {
     const int n = tile_c0 + col;
     float bias = 0.f;
-    if (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT) {
+    const bool post_bias = p.epilogue == CSMOE_EPI_ROUND_BIAS32_ACT;   // fp32 bias added to the ROUNDED product (cvmm + bias)
+    if (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias) {
       const void* bp = p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias;
-      if (bp) bias = DT<T>::ld((const T*)bp + n);
+      if (bp) bias = post_bias ? ((const float*)bp)[n] : DT<T>::ld((const T*)bp + n);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -120,9 +121,9 @@ __global__ void __launch_bounds__(256) gg_generic_kernel(GGArgs p) {
         float h = DT<T>::ld((const T*)p.aux + o);
         DT<T>::st((T*)p.C + o, g * (p.act == CSMOE_ACT_QUICK_GELU ? quick_gelu_grad_rounded<T>(h) : act_bwd(h, p.act)));
       } else {
-        float h = DT<T>::rnd(v + bias);
-        DT<T>::st((T*)p.C + o, h);
-        if (p.epilogue == CSMOE_EPI_BIAS_ACT && p.C2)
+        float h = post_bias ? DT<T>::rnd(v) + bias : DT<T>::rnd(v + bias);
+        if (p.C) DT<T>::st((T*)p.C + o, h);
+        if ((p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias) && p.C2)
           DT<T>::st((T*)p.C2 + o, p.act == CSMOE_ACT_QUICK_GELU ? quick_gelu_rounded<T>(h) : act_fwd(h, p.act));
       }
     }

@@ -109,9 +109,9 @@ __global__ void __launch_bounds__(256) router_select_kernel(const void* scores, 
   } else if (mode == CSMOE_SEL_RAW) {
     denom = round_dt(vsum, dtype);
     wk = round_dt(myv / denom, dtype);
-  } else {  // SIGMOID
-    denom = round_dt(vsum, dtype) + 1e-20f;
-    wk = round_dt(myv / denom, dtype);
+  } else {  // SIGMOID: fp32 sum of the K sigmoids (+1e-20), fp32 quotient
+    denom = vsum + 1e-20f;
+    wk = myv / denom;
   }
   if (lane < K) { w[(int64_t)t * K + lane] = wk; idx[(int64_t)t * K + lane] = myi; }
 }
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scor
     float denom;
     if (mode == CSMOE_SEL_SOFTMAX || mode == CSMOE_SEL_TOPK_SIGMOID) denom = round_sum_bf16 ? (float)(bf16)ssum : ssum;
     else if (mode == CSMOE_SEL_RAW) denom = round_dt(ssum, dtype);
-    else denom = round_dt(ssum, dtype) + 1e-20f;
+    else denom = ssum + 1e-20f;
     float dot = wave_sum(mydw * myv);
     dv = mydw / denom - dot / (denom * denom);
     if (mode == CSMOE_SEL_SIGMOID) dv *= myv * (1.f - myv);

@@ -175,7 +175,7 @@ class EPFFN(torch.autograd.Function):
         lb = ops.bin_tokens(local_expert_ids(plan).view(-1, 1), tab.E)
         rs = ops.dispatch_rows(recv, lb)
         hpre, hact = ops.grouped_gemm(rs, tab.w1_ptrs, tab.layout, tab.D, tab.F, lb.offsets, tab.E, bias_ptrs=tab.b1_ptrs,
-                                      epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True)
+                                      epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True, want_c=tab.act != L.ACT_RELU)
         ys = ops.grouped_gemm(hact, tab.w2_ptrs, tab.layout, tab.F, tab.Dout, lb.offsets, tab.E, bias_ptrs=tab.b2_ptrs,
                               epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
         y = a2a_rows(ops.dispatch_rows(ys, _Unsort(lb)), plan.recv_splits, plan.send_splits, group)
@@ -197,7 +197,8 @@ class EPFFN(torch.autograd.Function):
         T = dout.shape[0]
         dy, dw = ops.combine_bwd(dout.contiguous(), y, bins, ctx.w, want_dw=ctx.needs_input_grad[1])
         dys = ops.dispatch_rows(a2a_rows(dy, plan.send_splits, plan.recv_splits, group), lb)
-        dh = ops.grouped_gemm(dys, tab.w2_ptrs, L.B_KN, tab.F, tab.F, lb.offsets, E, epilogue=L.EPI_ACTGRAD, act=tab.act, aux=hpre)
+        dh = ops.grouped_gemm(dys, tab.w2_ptrs, L.B_KN, tab.F, tab.F, lb.offsets, E, epilogue=L.EPI_ACTGRAD, act=tab.act,
+                              aux=hpre if hpre is not None else hact)
         pg = [None] * ctx.n_params
         if any(ctx.needs_input_grad[7:]):
             es = torch.tensor([], dtype=pd).element_size()
@@ -255,7 +256,7 @@ class EPFFNChunked(torch.autograd.Function):
             rs = ops.dispatch_rows(r, lb)
             hpre, hact = ops.grouped_gemm(rs, tab.w1_ptrs[cp.e0:cp.e1], tab.layout, tab.D, tab.F, lb.offsets, Ec,
                                           bias_ptrs=None if tab.b1_ptrs is None else tab.b1_ptrs[cp.e0:cp.e1],
-                                          epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True)
+                                          epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True, want_c=tab.act != L.ACT_RELU)
             ys = ops.grouped_gemm(hact, tab.w2_ptrs[cp.e0:cp.e1], tab.layout, tab.F, tab.Dout, lb.offsets, Ec,
                                   bias_ptrs=None if tab.b2_ptrs is None else tab.b2_ptrs[cp.e0:cp.e1],
                                   epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
@@ -316,7 +317,7 @@ class EPFFNChunked(torch.autograd.Function):
             Ec = e1 - e0
             dys = ops.dispatch_rows(r, lb)
             dh = ops.grouped_gemm(dys, tab.w2_ptrs[e0:e1], L.B_KN, tab.F, tab.F, lb.offsets, Ec, epilogue=L.EPI_ACTGRAD, act=tab.act,
-                                  aux=hpre)
+                                  aux=hpre if hpre is not None else hact)
             if need_dx:                                  # input gradient first: its return trip overlaps this group's weight gradients
                 dxs_s = ops.grouped_gemm(dh, tab.w1_ptrs[e0:e1], L.B_KN, tab.D, tab.D, lb.offsets, Ec)
                 ret = ops.dispatch_rows(dxs_s, _Unsort(lb))

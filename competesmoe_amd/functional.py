@@ -243,6 +243,7 @@ class ExpertTable:
     b1_ptrs: Optional[torch.Tensor] = None
     b2_ptrs: Optional[torch.Tensor] = None
     param_dtype: torch.dtype = torch.float32   # dtype of the gradients handed back
+    epi1: int = L.EPI_BIAS_ACT                 # epilogue of the first GEMM (EPI_ROUND_BIAS32_ACT: fp32 b1 table, pretrain autocast)
 
 
 # Operand-dtype copies of fp32 master weights kept across calls while the parameter is unchanged (same storage, same autograd
@@ -303,8 +304,10 @@ def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residua
     xs = ops.dispatch_tokens(x2, bins)
     ld1 = tab.D if tab.layout == L.B_NK else tab.F
     ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
+    # ReLU: act'(pre) = (act(pre) > 0), so the pre-activation is neither written (1.44 GB at the headline shape) nor re-read by the
+    # dH epilogue; every other activation keeps it
     hpre, hact = ops.grouped_gemm(xs, tab.w1_ptrs, tab.layout, ld1, tab.F, bins.offsets, tab.E, bias_ptrs=tab.b1_ptrs,
-                                  epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True)
+                                  epilogue=tab.epi1, act=tab.act, want_c2=True, want_c=tab.act != L.ACT_RELU)
     if before_gemm2 is not None:
         torch.cuda.current_stream().wait_stream(before_gemm2)
     y = ops.grouped_gemm(hact, tab.w2_ptrs, tab.layout, ld2, tab.Dout, bins.offsets, tab.E, bias_ptrs=tab.b2_ptrs,
@@ -345,12 +348,12 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
     T = dout.shape[0]
     dev = dout.device
     E = tab.E
-    dy, dw = ops.combine_bwd(dout.contiguous(), y if need_dw else None, bins, w, want_dw=need_dw, act_dtype=hpre.dtype)
+    dy, dw = ops.combine_bwd(dout.contiguous(), y if need_dw else None, bins, w, want_dw=need_dw, act_dtype=hact.dtype)
     ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
     ld1 = tab.D if tab.layout == L.B_NK else tab.F
     # dH = dY @ W2 (+ activation backward in the epilogue)
     dh = ops.grouped_gemm(dy, tab.w2_ptrs, _flip(tab.layout), ld2, tab.F, bins.offsets, E, epilogue=L.EPI_ACTGRAD,
-                          act=tab.act, aux=hpre)
+                          act=tab.act, aux=hpre if hpre is not None else hact)
     grads = None
     if need_params:
         pd = tab.param_dtype
@@ -479,7 +482,14 @@ class MoEFFNPacked(torch.autograd.Function):
         es = k_op.element_size()
         b_op = None
         b1 = None
-        if bias is not None:
+        epi1 = L.EPI_BIAS_ACT
+        if bias is not None and bias.dtype == torch.float32 and op == torch.bfloat16:
+            # `scores = cvmm(...) + self.bias[sel]` under autocast (moe.py:400-405): the fp32 master bias is added to the ALREADY
+            # ROUNDED bf16 product in fp32, the activation sees that sum, the next cvmm rounds it
+            b_op = bias.contiguous()
+            b1 = ops.ptr_table(b_op, E, F * 4)
+            epi1 = L.EPI_ROUND_BIAS32_ACT
+        elif bias is not None:
             b_op = bias.contiguous() if bias.dtype == op else bias.to(op)
             b1 = ops.ptr_table(b_op, E, F * es)
         ob = None
@@ -487,7 +497,7 @@ class MoEFFNPacked(torch.autograd.Function):
             ob = o_bias.contiguous() if o_bias.dtype == op else o_bias.to(op)
         tab = ExpertTable(E=E, D=D, F=F, Dout=Dout, layout=L.B_KN, act=act,
                           w1_ptrs=ops.ptr_table(k_op, E, D * F * es), w2_ptrs=ops.ptr_table(v_op, E, F * Dout * es),
-                          b1_ptrs=b1, b2_ptrs=None, param_dtype=keys.dtype)
+                          b1_ptrs=b1, b2_ptrs=None, param_dtype=keys.dtype, epi1=epi1)
         out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, ob, residual=None if residual is None else residual.contiguous(),
                                   before_gemm2=side)
         ctx.has_residual = residual is not None
@@ -540,8 +550,14 @@ class DenseFFN(torch.autograd.Function):
                 return c
             return t.to(op)
 
-        w1o, b1o, w2o, b2o = cast(w1), cast(b1), cast(w2), cast(b2)
-        hpre, hact = ops.dense_gemm(x2, w1o, layout, bias=b1o, epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True)
+        epi1 = L.EPI_BIAS_ACT
+        if b1 is not None and b1.dtype == torch.float32 and op == torch.bfloat16 and layout == L.B_KN:
+            # the pretrain stack's shared expert: cvmm output + fp32 master bias (see MoEFFNPacked)
+            w1o, b1o, w2o, b2o = cast(w1), b1.contiguous(), cast(w2), cast(b2)
+            epi1 = L.EPI_ROUND_BIAS32_ACT
+        else:
+            w1o, b1o, w2o, b2o = cast(w1), cast(b1), cast(w2), cast(b2)
+        hpre, hact = ops.dense_gemm(x2, w1o, layout, bias=b1o, epilogue=epi1, act=act, want_c2=True, want_c=act != L.ACT_RELU)
         y = ops.dense_gemm(hact, w2o, layout, bias=b2o, epilogue=L.EPI_BIAS if b2o is not None else L.EPI_PLAIN)
         ctx.save_for_backward(x2, w1o, w2o, hpre, hact)
         ctx.cfg = (act, layout, w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
@@ -552,7 +568,7 @@ class DenseFFN(torch.autograd.Function):
         x2, w1o, w2o, hpre, hact = ctx.saved_tensors
         act, layout, dt_w1, dt_b1, dt_w2, dt_b2 = ctx.cfg
         dy = dy.contiguous()
-        dh = ops.dense_gemm(dy, w2o, _flip(layout), epilogue=L.EPI_ACTGRAD, act=act, aux=hpre)
+        dh = ops.dense_gemm(dy, w2o, _flip(layout), epilogue=L.EPI_ACTGRAD, act=act, aux=hpre if hpre is not None else hact)
         gw1 = gb1 = gw2 = gb2 = dx = None
         if ctx.needs_input_grad[3]:
             gw2 = _dense_wgrad(dy, hact, dt_w2) if layout == L.B_NK else _dense_wgrad(hact, dy, dt_w2)

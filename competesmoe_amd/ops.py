@@ -389,26 +389,27 @@ def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: to
 # ------------------------------------------------------------------------------------------------ grouped GEMMs
 def grouped_gemm(A: torch.Tensor, b_ptrs: torch.Tensor, b_layout: int, ldb: int, N: int, offsets: torch.Tensor, E: int,
                  bias_ptrs: Optional[torch.Tensor] = None, epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE,
-                 aux: Optional[torch.Tensor] = None, want_c2: bool = False, force_generic: bool = False):
+                 aux: Optional[torch.Tensor] = None, want_c2: bool = False, force_generic: bool = False, want_c: bool = True):
+    """`want_c=False` (with want_c2 and EPI_BIAS_ACT): only the activated output is written and (None, C2) returned."""
     M, Kd = A.shape
-    Cm = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    Cm = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c else None
     C2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c2 else None
     with _timed("grouped_gemm_" + ("nt" if b_layout == L.B_NK else "nn"), 2.0 * M * N * Kd):
         L.check(lib.csmoe_grouped_gemm(A.data_ptr(), A.stride(0), b_ptrs.data_ptr(), b_layout, ldb, _ptr(bias_ptrs),
-                                       offsets.data_ptr(), E, M, N, Kd, Cm.data_ptr(), _ptr(C2), _ptr(aux), N, epilogue, act,
+                                       offsets.data_ptr(), E, M, N, Kd, _ptr(Cm), _ptr(C2), _ptr(aux), N, epilogue, act,
                                        _dt(A), int(force_generic), _stream()), "grouped_gemm")
     return (Cm, C2) if want_c2 else Cm
 
 
 def dense_gemm(A: torch.Tensor, B: torch.Tensor, b_layout: int, bias: Optional[torch.Tensor] = None,
                epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE, aux: Optional[torch.Tensor] = None, want_c2: bool = False,
-               force_generic: bool = False):
+               force_generic: bool = False, want_c: bool = True):
     M, Kd = A.shape
     N = B.shape[0] if b_layout == L.B_NK else B.shape[1]
-    Cm = torch.empty(M, N, dtype=A.dtype, device=A.device)
+    Cm = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c else None
     C2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c2 else None
     L.check(lib.csmoe_dense_gemm(A.data_ptr(), A.stride(0), B.data_ptr(), b_layout, B.stride(0), _ptr(bias), M, N, Kd,
-                                 Cm.data_ptr(), _ptr(C2), _ptr(aux), N, epilogue, act, _dt(A), int(force_generic), _stream()),
+                                 _ptr(Cm), _ptr(C2), _ptr(aux), N, epilogue, act, _dt(A), int(force_generic), _stream()),
             "dense_gemm")
     return (Cm, C2) if want_c2 else Cm
 
@@ -459,7 +460,10 @@ def dense_colsum(G: torch.Tensor, out_dtype=None) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ affinity
-SOFTPLUS_PRECISE = os.environ.get("CSMOE_SOFTPLUS_PRECISE", "1") != "0"    # exp / log1p as torch evaluates them (A/B: 0 = hardware exp / log)
+# softplus of the affinity kernels: hardware exp / log (default) or expf / log1pf as torch evaluates them (=1).  A/B on every
+# competition fixture (tools/parity_report.py, profiles/r02/parity_report.txt): the same rows route differently from the reference
+# with either form (the bf16 near-ties of the LLaVA stack's x.dtype affinities), none with fp32 affinities -- so the fast form stays.
+SOFTPLUS_PRECISE = os.environ.get("CSMOE_SOFTPLUS_PRECISE", "0") == "1"
 
 
 def softplus_mean(y: torch.Tensor, aff_dtype=None) -> torch.Tensor:

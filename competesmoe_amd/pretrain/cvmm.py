@@ -56,7 +56,8 @@ class _CVMM(torch.autograd.Function):
         ys = ops.grouped_gemm(xs, ptrs, L.B_KN, Dout, Dout, bins.offsets, E)
         T = bins.n // bins.K
         if weight is not None:
-            out = ops.combine(ys, bins, None, weight.reshape(T, bins.K).float().contiguous(), L.COMBINE_DOT, T)
+            # `reduction_weight.type_as(res) @ res` (cvmm.py:483): the K weights enter in the op dtype
+            out = ops.combine(ys, bins, None, weight.reshape(T, bins.K).to(op).float().contiguous(), L.COMBINE_DOT, T)
         else:                   # back to the flat (t*K+k) order
             out = ops.dispatch_rows(ys, ops.Bins(None, None, bins.slot_of, None, bins.n, bins.E, 1))
         ctx.save_for_backward(xs, k_op, ys if weight is not None else None, weight)
@@ -71,7 +72,7 @@ class _CVMM(torch.autograd.Function):
         g = g.reshape(-1, Dout).to(k_op.dtype).contiguous()
         dw = None
         if weight is not None:
-            gs, dwf = ops.combine_bwd(g, ys, bins, weight.reshape(T, bins.K).float().contiguous())
+            gs, dwf = ops.combine_bwd(g, ys, bins, weight.reshape(T, bins.K).to(k_op.dtype).float().contiguous())
             dw = dwf.view_as(weight).to(weight.dtype)
         else:
             gs = ops.dispatch_rows(g, ops.Bins(None, None, bins.perm, None, bins.n, bins.E, 1))

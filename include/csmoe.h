@@ -35,7 +35,8 @@ enum {
   CSMOE_SEL_SOFTMAX = 0,  /* softmax(fp32) -> topk -> w/sum          moe_model/model/moe/moe.py:129-130, smoe.py:44      */
   CSMOE_SEL_RAW = 1,      /* topk on raw scores -> w/sum (competition) moe_model/model/moe/competesmoe.py:253-255          */
   CSMOE_SEL_TOPK_SOFTMAX = 2, /* topk(logits) -> softmax over the K  moe_pretrain_model/layers/moe/deepseekv2.py:140-142 */
-  CSMOE_SEL_SIGMOID = 3,  /* topk(sigmoid) -> w/(sum+1e-20)           moe_pretrain_model/layers/moe/deepseekv3.py:147-151 */
+  CSMOE_SEL_SIGMOID = 3,  /* topk(sigmoid in the scores' dtype) -> w/(fp32 sum+1e-20), fp32 quotient (under CUDA autocast `sum` is an
+                             fp32-policy op)                          moe_pretrain_model/layers/moe/deepseekv3.py:147-151 */
   CSMOE_SEL_TOPK_SIGMOID = 4 /* topk(logits) -> sigmoid(v / sel_param) -> w/sum   (`norm_sigmoid` + `scale_weight`,
                                 moe_pretrain_model/layers/moe/competesmoe.py:476-483)                                    */
 };
@@ -61,8 +62,13 @@ enum {
 enum {
   CSMOE_EPI_PLAIN = 0,     /* C = round(acc)                                                         */
   CSMOE_EPI_BIAS = 1,      /* C = round(acc + bias_e[n])                                            */
-  CSMOE_EPI_BIAS_ACT = 2,  /* C = round(acc + bias_e[n]);  C2 = round(act(C))   (bias may be null)  */
-  CSMOE_EPI_ACTGRAD = 3    /* C = round(round(acc) * act'(aux[m,n]))             (GELU/ReLU backward) */
+  CSMOE_EPI_BIAS_ACT = 2,  /* C = round(acc + bias_e[n]);  C2 = round(act(C))   (bias may be null; C may be null when only
+                              the activated output is kept: for ReLU act'(pre) = (act(pre) > 0), so ACTGRAD takes C2 as aux) */
+  CSMOE_EPI_ACTGRAD = 3,   /* C = round(round(acc) * act'(aux[m,n]))             (GELU/ReLU backward) */
+  CSMOE_EPI_ROUND_BIAS32_ACT = 4 /* u = round(acc) + bias_e[n] with an FP32 bias table; C = round(u) (may be null); C2 = round(act(u)):
+                              the pretrain stack's `scores = cvmm(...) + bias[sel]` under autocast -- the cvmm output is already
+                              rounded to bf16, the fp32 master bias promotes the sum to fp32, the activation runs on that and the
+                              next cvmm rounds once more (moe_pretrain_model/layers/moe/moe.py:400-405) */
 };
 
 int csmoe_version(void);

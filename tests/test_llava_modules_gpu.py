@@ -119,7 +119,10 @@ def test_layer_matches_reference_golden(case, tag):
             if dt == torch.float32:
                 assert not bad.any()
             else:
-                assert bad.float().mean() <= 0.10, bad.float().mean()
+                # observed on every bf16 competition fixture: 6 of 128 rows = 0.047 (profiles/r02/parity_report.txt, identical with
+                # the precise and the fast softplus); bound = observed + one row
+                print(f"bf16 competition rows routed differently: {float(bad.float().mean()):.4f}")
+                assert bad.float().mean() <= 0.055, bad.float().mean()
                 if bad.any():
                     a = torch.gather(ga, -1, aidx.reshape(-1, K).long())[bad].sort(-1).values
                     b = torch.gather(ga, -1, gai)[bad].sort(-1).values

@@ -97,9 +97,9 @@ def ref_select(scores, K, mode, round_bf16):
         if round_bf16:
             den = den.bfloat16().float()
         w = sv / den
-    else:
-        den = v.sum(-1, keepdim=True).to(dt).float() + 1e-20
-        w = (v / den).to(dt).float()
+    else:               # sigmoid in the scores' dtype, fp32 sum (+1e-20), fp32 quotient
+        den = v.sum(-1, keepdim=True) + 1e-20
+        w = v / den
     return sm, idx, w
 
 
@@ -129,7 +129,7 @@ def test_router_select(T, E, K, mode, dtype):
             bb = torch.gather(rsm, -1, ridx)[mism].sort(-1).values
             assert torch.allclose(a, bb, rtol=1e-6)
     ok = (idx.cpu().long() == ridx).all(-1)
-    assert torch.allclose(w.cpu()[ok], rw[ok], rtol=(1e-5 if dtype == torch.float32 or mode in (0, 2) else 2 ** -7), atol=1e-7)
+    assert torch.allclose(w.cpu()[ok], rw[ok], rtol=(1e-5 if dtype == torch.float32 or mode in (0, 2, 3, 4) else 2 ** -7), atol=1e-7)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
@@ -229,6 +229,42 @@ def test_grouped_gemm_plain_and_bias_act(E, M, N, Kd, b_layout, dtype, force_gen
                          force_generic=force_generic)
     rc, _ = ref_rowspace(A, Bs, b_layout, off, None, 3, 2, aux)
     assert torch.allclose(c.float(), rc.float(), **tol)
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("E,M,N,Kd", [(4, 100, 64, 64), (8, 1500, 256, 192), (8, 3000, 512, 320)])
+def test_grouped_gemm_activated_output_only_and_post_rounding_bias(E, M, N, Kd, force_generic):
+    """(1) C == null with EPI_BIAS_ACT: only the activated output is written, bit-identical to the two-output launch (what the
+    ReLU experts of the pretrain stack use: act'(pre) = (act(pre) > 0), so ACTGRAD with aux = hact equals aux = hpre).
+    (2) EPI_ROUND_BIAS32_ACT: act(round(acc) + fp32 bias), the pretrain stack's `cvmm(...) + bias[sel]` under autocast."""
+    g = torch.Generator().manual_seed(M + N + 1)
+    off = make_groups(E, M, seed=M)
+    offd = off.to(DEV)
+    A = torch.randn(M, Kd, generator=g).bfloat16().to(DEV)
+    Bs = [(torch.randn(Kd, N, generator=g) / math.sqrt(Kd)).bfloat16().to(DEV) for _ in range(E)]
+    bias = [(torch.randn(N, generator=g) * 0.5).bfloat16().to(DEV) for _ in range(E)]
+    bias32 = [(torch.randn(N, generator=g) * 0.5).to(DEV) for _ in range(E)]
+    bp = ops.ptr_array(Bs, DEV)
+    c, c2 = ops.grouped_gemm(A, bp, 1, N, N, offd, E, bias_ptrs=ops.ptr_array(bias, DEV), epilogue=L.EPI_BIAS_ACT, act=L.ACT_RELU,
+                             want_c2=True, force_generic=force_generic)
+    none, only = ops.grouped_gemm(A, bp, 1, N, N, offd, E, bias_ptrs=ops.ptr_array(bias, DEV), epilogue=L.EPI_BIAS_ACT,
+                                  act=L.ACT_RELU, want_c2=True, want_c=False, force_generic=force_generic)
+    assert none is None and torch.equal(only, c2)
+    dy = torch.randn(M, Kd, generator=g).bfloat16().to(DEV)
+    Wt = [(torch.randn(N, Kd, generator=g) / math.sqrt(Kd)).bfloat16().to(DEV) for _ in range(E)]     # [N, Kd]: dh = dy @ Wt^T
+    d1 = ops.grouped_gemm(dy, ops.ptr_array(Wt, DEV), 0, Kd, N, offd, E, epilogue=L.EPI_ACTGRAD, act=L.ACT_RELU, aux=c,
+                          force_generic=force_generic)
+    d2 = ops.grouped_gemm(dy, ops.ptr_array(Wt, DEV), 0, Kd, N, offd, E, epilogue=L.EPI_ACTGRAD, act=L.ACT_RELU, aux=c2,
+                          force_generic=force_generic)
+    assert torch.equal(d1, d2)
+    # post-rounding fp32 bias
+    pre, act = ops.grouped_gemm(A, bp, 1, N, N, offd, E, bias_ptrs=ops.ptr_array(bias32, DEV), epilogue=L.EPI_ROUND_BIAS32_ACT,
+                                act=L.ACT_RELU, want_c2=True, force_generic=force_generic)
+    plain = ops.grouped_gemm(A, bp, 1, N, N, offd, E, force_generic=force_generic)            # round(acc)
+    u = plain.float()
+    for e in range(E):
+        u[int(off[e]):int(off[e + 1])] += bias32[e]
+    assert torch.equal(pre, u.bfloat16()) and torch.equal(act, torch.relu(u).bfloat16())
 
 
 @pytest.mark.parametrize("b_layout", [0, 1])

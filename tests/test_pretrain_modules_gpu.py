@@ -23,7 +23,7 @@ if torch.cuda.is_available():
     from competesmoe_amd.pretrain import get_moe, cvmm, cvmm_prepare_sel2
 
 CASES = ["smoe", "smoe_bias", "competesmoe_router", "competesmoe_comp", "competesmoe_comp_hybrid", "deepseekv2", "deepseekv3"]
-BF16_OUT, BF16_BAD_ROWS, BF16_GRAD = 2e-3, 0.03, 2e-2        # provisional: calibrated from tools/parity_report.py
+BF16_OUT, BF16_BAD_ROWS, BF16_GRAD = 2e-4, 0.01, 6e-3        # observed maxima: 5.8e-5, 0.0078 (deepseekv3 sigmoid ties), 4.3e-3
 
 
 def build(fx):
@@ -154,11 +154,11 @@ def test_cvmm_api_matches_the_reference_kernels(tag):
         sel2.out_index = None
         out = cvmm(scores, sel2, values)                              # [2, T/2, D]
     assert scores.dtype == fx["scores"].dtype and out.dtype == fx["output"].dtype
-    tol = 1e-5 if not bf16 else 2e-3
+    tol = 1e-5 if not bf16 else 2e-4
     assert rel_l2(scores, fx["scores"].to(DEV)) <= tol, rel_l2(scores, fx["scores"].to(DEV))
     assert rel_l2(out, fx["output"].to(DEV)) <= tol, rel_l2(out, fx["output"].to(DEV))
     (out.float() * fx["dy"].to(DEV)).sum().backward()
-    gt = 4e-5 if not bf16 else 1.5e-2
+    gt = 4e-5 if not bf16 else 6e-3
     for name, t in (("x", x), ("keys", keys), ("values", values), ("w", w)):
         assert rel_l2(t.grad, fx["grads"][name].to(DEV)) <= gt, (name, rel_l2(t.grad, fx["grads"][name].to(DEV)))
 

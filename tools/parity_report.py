@@ -5,15 +5,15 @@ Prints, per fixture: relative L2 of the output, the fraction of rows routed diff
 O(1)), relative L2 over the rows routed alike, the aux / regularisation losses, and relative L2 of every gradient.  The numbers
 calibrate the tolerances written in tests/test_*_gpu.py and are kept under profiles/rNN/parity_report.txt.
 
-    python tools/parity_report.py [--softplus-fast]      (CSMOE_SOFTPLUS_PRECISE=0 for the A/B of the affinity kernel's math)
+    python tools/parity_report.py [--softplus-precise]   (CSMOE_SOFTPLUS_PRECISE=1: the A/B of the affinity kernel's exp / log)
 """
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-if "--softplus-fast" in sys.argv:
-    os.environ["CSMOE_SOFTPLUS_PRECISE"] = "0"
+if "--softplus-precise" in sys.argv:
+    os.environ["CSMOE_SOFTPLUS_PRECISE"] = "1"
 
 import torch  # noqa: E402
 
@@ -48,9 +48,19 @@ def llava():
             if "aff_selected" in fx and hasattr(layer, "competition_policy"):
                 with torch.no_grad():
                     r = layer.competition_policy(fx["x"].to(DEV))
-                idx = r[1].cpu().long()
-                mism = (idx.sort(-1).values != fx["aff_selected"].sort(-1).values).any(-1)
-                line.append(f"affinity-topk-set-mismatch {float(mism.float().mean()):.4f}")
+                idx = r[1].cpu().long().reshape(-1, r[1].shape[-1])
+                gi = fx["aff_selected"].reshape(idx.shape)
+                ga = fx["aff_scores"].reshape(idx.shape[0], -1).float()
+                aff = r[3].cpu().float().reshape(ga.shape)
+                mism = (idx.sort(-1).values != gi.sort(-1).values).any(-1)
+                K = idx.shape[-1]
+                srt = ga.sort(-1, descending=True).values
+                tie = srt[:, K - 1] == srt[:, K]                    # the reference's own scores tie at the top-K boundary
+                ulp = (aff != ga).any(-1)                          # our affinity differs from the reference's somewhere in the row
+                line.append(f"affinity-topk-set-mismatch {float(mism.float().mean()):.4f} "
+                            f"(of those: exact tie in the reference's scores {int((mism & tie).sum())}, "
+                            f"1-ulp affinity difference {int((mism & ~tie & ulp).sum())}, other {int((mism & ~tie & ~ulp).sum())}; "
+                            f"rows with any affinity difference {int(ulp.sum())}/{ulp.numel()})")
             ((out.float() * fx["dy"].to(DEV).float()).sum() + aux.float()).backward()
             line.append(f"dx {rel_l2(x.grad, fx['x_grad'].to(DEV)):.2e}")
             worst = 0.0
@@ -92,6 +102,6 @@ def pretrain():
 
 
 if __name__ == "__main__":
-    print("CSMOE_SOFTPLUS_PRECISE =", os.environ.get("CSMOE_SOFTPLUS_PRECISE", "1"))
+    print("CSMOE_SOFTPLUS_PRECISE =", os.environ.get("CSMOE_SOFTPLUS_PRECISE", "0"))
     llava()
     pretrain()
