@@ -74,8 +74,17 @@ def _need_cuda(*ts):
             raise ValueError("csmoe: tensors must live on the GPU (the HIP path has no CPU fallback)")
 
 
+def _capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def ptr_array(tensors: Sequence[Optional[torch.Tensor]], device) -> torch.Tensor:
-    """Device array of raw pointers (int64) -- the per-expert weight table handed to the grouped GEMM."""
+    """Device array of raw pointers (int64) -- the per-expert weight table handed to the grouped GEMM.  A pageable host-to-device
+    copy: not allowed inside a hipGraph capture (competesmoe_amd/graphs.py) -- the layers cache their tables by parameter address,
+    so one eager step before the capture builds them."""
+    if _capturing():
+        raise RuntimeError("competesmoe_amd: a per-expert pointer table would have to be built inside a graph capture "
+                           "(host-to-device copy); run one eager step with the same parameters first (graphs.GraphedStep does)")
     return torch.tensor([0 if t is None else t.data_ptr() for t in tensors], dtype=torch.int64, device=device)
 
 
@@ -179,13 +188,20 @@ def ptr_table(buf: torch.Tensor, n: int, stride_bytes: int) -> torch.Tensor:
     reference's small LLaVA shapes a step is bound by the number of launches)."""
     base = buf.data_ptr()
     full = (base, n, stride_bytes, buf.device)
-    tab = _PTR_TABLES.get(full)       # the caching allocator hands the same addresses out step after step: usually a hit, no launch
+    cap = _capturing()
+    tab = None if cap else _PTR_TABLES.get(full)   # the caching allocator hands the same addresses out step after step: usually a hit
     if tab is not None:
         return tab
     key = (n, stride_bytes, buf.device)
     offs = _STRIDE_TABLES.get(key)
     if offs is None:
+        if cap:
+            raise RuntimeError("competesmoe_amd: a stride table is missing inside a graph capture; run one eager step first")
         offs = _STRIDE_TABLES[key] = torch.arange(n, device=buf.device, dtype=torch.int64) * stride_bytes
+    if cap:
+        # inside a capture the add is a graph node (recomputed by every replay); it must not enter the address-keyed cache: kernels
+        # do not run while capturing, and the graph's private pool re-uses addresses the eager allocator also hands out
+        return offs + base
     if len(_PTR_TABLES) >= 512:
         _PTR_TABLES.clear()
     tab = _PTR_TABLES[full] = offs + base
