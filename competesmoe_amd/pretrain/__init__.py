@@ -6,7 +6,8 @@ from .moe import MoE
 from .smoe import SMoeLayer
 from .competesmoe import CompeteSMoE
 from .deepseek import DeepSeekV2, DeepSeekV3
+from .smoe_perturbed import MoEPerturbedCosingGating, Selection
 from .block import MoEBlock
 
 __all__ = ["register_moe", "get_moe", "MOE_REGISTRY", "LoggingLayer", "RegularizedLayer", "OncePerIterLayer", "CVMMSel", "cvmm",
-           "cvmm_prepare_sel2", "MoE", "SMoeLayer", "CompeteSMoE", "DeepSeekV2", "DeepSeekV3", "MoEBlock"]
+           "cvmm_prepare_sel2", "MoE", "SMoeLayer", "CompeteSMoE", "DeepSeekV2", "DeepSeekV3", "MoEPerturbedCosingGating", "Selection", "MoEBlock"]

@@ -55,24 +55,29 @@ class _CVMM(torch.autograd.Function):
             xs = ops.dispatch_rows(xf, bins)
         ys = ops.grouped_gemm(xs, ptrs, L.B_KN, Dout, Dout, bins.offsets, E)
         T = bins.n // bins.K
+        rbins = None
         if weight is not None:
-            # `reduction_weight.type_as(res) @ res` (cvmm.py:483): the K weights enter in the op dtype
-            out = ops.combine(ys, bins, None, weight.reshape(T, bins.K).to(op).float().contiguous(), L.COMBINE_DOT, T)
+            # `res.view(*w.shape, N)`, `w.unsqueeze(-2).type_as(res) @ res` (cvmm.py:481-483): the reduction runs over the LAST dim of
+            # the weights -- all K selections of a token in the MoE layers, the K experts of ONE head in the MoE attention
+            # projections (w [B, N, heads, K]: flat slot (t * heads + h) * K + k) -- and the weights enter in the op dtype
+            Kr = weight.shape[-1]
+            rbins = bins if Kr == bins.K else ops.Bins(bins.counts, bins.offsets, bins.perm, bins.slot_of, bins.n, bins.E, Kr)
+            out = ops.combine(ys, rbins, None, weight.reshape(-1, Kr).to(op).float().contiguous(), L.COMBINE_DOT, bins.n // Kr)
         else:                   # back to the flat (t*K+k) order
             out = ops.dispatch_rows(ys, ops.Bins(None, None, bins.slot_of, None, bins.n, bins.E, 1))
         ctx.save_for_backward(xs, k_op, ys if weight is not None else None, weight)
-        ctx.meta = (bins, rows_are_slots, ptrs, keys.dtype, x.shape, x.dtype, T)
+        ctx.meta = (bins, rows_are_slots, ptrs, keys.dtype, x.shape, x.dtype, T, rbins)
         return out
 
     @staticmethod
     def backward(ctx, g):
         xs, k_op, ys, weight = ctx.saved_tensors
-        bins, rows_are_slots, ptrs, kd, xshape, xdt, T = ctx.meta
+        bins, rows_are_slots, ptrs, kd, xshape, xdt, T, rbins = ctx.meta
         E, Din, Dout = k_op.shape
         g = g.reshape(-1, Dout).to(k_op.dtype).contiguous()
         dw = None
         if weight is not None:
-            gs, dwf = ops.combine_bwd(g, ys, bins, weight.reshape(T, bins.K).to(k_op.dtype).float().contiguous())
+            gs, dwf = ops.combine_bwd(g, ys, rbins, weight.reshape(-1, rbins.K).to(k_op.dtype).float().contiguous())
             dw = dwf.view_as(weight).to(weight.dtype)
         else:
             gs = ops.dispatch_rows(g, ops.Bins(None, None, bins.perm, None, bins.n, bins.E, 1))
@@ -96,5 +101,5 @@ def cvmm(x: torch.Tensor, sel: CVMMSel, keys: torch.Tensor) -> torch.Tensor:
     rows_are_slots = sel.out_index is None      # second-call convention: sel_index <- out_index, out_index <- None
     out = _CVMM.apply(x, keys, sel.reduction_weight, sel.bins, rows_are_slots)
     if sel.reduction_weight is not None:
-        return out.view(*sel.reduction_weight.shape[:-1], keys.shape[-1])
+        return out.view(*sel.reduction_weight.shape[:-1], keys.shape[-1])      # [.., heads, out] for [B, N, heads, K] weights
     return out.view(*sel.sel.shape, keys.shape[-1])

@@ -468,3 +468,54 @@ def pretrain_block_forward(x, ln_weight, ln_bias, eps, moe_forward):
     xn = F.layer_norm(x, (x.shape[-1],), ln_weight, ln_bias, eps)
     out = moe_forward(xn)
     return x + out, out, xn
+
+
+# --------------------------------------------------------------------------------------------
+# smoe_perturbed and the MoE attention projections (moe_pretrain_model/layers/moe/smoe_perturbed.py;
+# layers/transformer/full_moe_relative_attention.py:267-300, 355-388) -- SURVEY.md section 8 (f4)
+# --------------------------------------------------------------------------------------------
+def perturbed_gate(x, expert_sel, embeddings_renormed, op_dtype=None, theta=0.1):
+    """compute_gate (smoe_perturbed.py:148-160) AFTER the in-place, no-grad renormalisation of `expert_embeddings`
+    (`emb *= 1.5 / (|emb| + theta)`), which the caller applies to the parameter first (`renorm_embeddings`).  `op_dtype` = bf16
+    restates the CUDA-autocast run: F.linear and torch.matmul round their operands and results to bf16, `norm` is an fp32-policy
+    op, `.type_as(mat1)` makes the logits bf16."""
+    if op_dtype is not None:
+        reduced = F.linear(x.to(op_dtype), expert_sel.to(op_dtype))
+        m1 = reduced.float() / (reduced.float().norm(p=2, dim=-1, keepdim=True) + theta)
+        logits = torch.matmul(m1.to(op_dtype), embeddings_renormed.float().transpose(0, 1).to(op_dtype)).type_as(reduced)
+    else:
+        reduced = F.linear(x, expert_sel)
+        m1 = reduced.float() / (reduced.norm(p=2, dim=-1, keepdim=True) + theta)
+        logits = torch.matmul(m1, embeddings_renormed.float().transpose(0, 1)).type_as(reduced)
+    ok = logits.isfinite()
+    return torch.where(ok, logits, torch.where(ok, logits, torch.full_like(logits, float("inf"))).min())
+
+
+def renorm_embeddings(emb, theta=0.1):
+    return emb * (1.5 / (emb.norm(p=2.0, dim=-1, keepdim=True) + theta))
+
+
+def top_softmax(gate_softmax, k):
+    """`_keepTopk` / att_forward :209-214: top-k of the softmax VALUES (indices without gradient), softmax over the k."""
+    idx = topk_lowest_index(gate_softmax.detach(), k)[1]
+    return torch.softmax(torch.gather(gate_softmax, -1, idx), dim=-1), idx
+
+
+def attention_projection(x, expert_sel, embeddings_renormed, experts, heads, n_experts, k, op_dtype, temperature=0.3,
+                         forced_index=None):
+    """att_forward + compute_moe (smoe_perturbed.py:199-226): per head the top-k of softmax(gate / T) over that head's experts;
+    out[b,n,h] = sum_k val[b,n,h,k] * x[b,n] @ experts[h * E + index[b,n,h,k]] as ONE cvmm with reduction weights [B,N,heads,k]."""
+    B, N, _ = x.shape
+    logits = perturbed_gate(x, expert_sel, embeddings_renormed, None if op_dtype == torch.float32 else op_dtype)
+    logits = logits.view(B, N, heads, -1)
+    sm = F.softmax((logits / temperature).float(), dim=-1).to(x.dtype)
+    val, index = top_softmax(sm, k)
+    if forced_index is not None:
+        index = forced_index
+        val = torch.softmax(torch.gather(sm, -1, index), dim=-1)
+    gid = (torch.arange(heads) * n_experts).view(1, 1, heads, 1) + index            # global expert ids
+    flat = gid.flatten(-2, -1)                                                      # [B, N, heads*k]
+    _, _, perm = bin_tokens(flat, experts.shape[0])
+    ssel = flat.flatten()[perm]
+    out = cvmm_ref(x, ssel, perm // (heads * k), perm, experts, op_dtype, reduction_weight=val)
+    return out, val, index, logits

@@ -55,6 +55,9 @@ def run_case(name, moe_name, bf16, *, B=2, N=64, D=64, E=8, F_=32, K=2, competit
     try:
         layer = get_moe(moe_name)(D, E, F_, n_heads=K, activation=F.relu, bias=bias, log_interval=None, args=args)
         layer.train()
+        if hasattr(layer, "expert_embeddings"):      # smoe_perturbed leaves it torch.empty (smoe_perturbed.py:100-104)
+            with torch.no_grad():
+                layer.expert_embeddings.copy_(torch.randn(layer.expert_embeddings.shape, generator=torch.Generator().manual_seed(seed + 9)))
         if bias:
             g0 = torch.Generator().manual_seed(seed + 5)
             for p in (layer.bias, layer.o_bias, getattr(layer, "bias_shared", None)):
@@ -159,6 +162,42 @@ def cvmm_kernel_case(bf16):
     print(f"wrote pretrain_cvmm_kernels_{tag}.pt", out.dtype, scores.dtype)
 
 
+def attention_projection_case(bf16):
+    """MoE attention projection: the layer exactly as FullMoeRelativeAttentionCore.create_param_block builds
+    it (full_moe_relative_attention.py:267-300: n_experts = experts per head x heads, expert_size = 1, is_att = True), then the two
+    calls the attention makes: sel = att_forward(x, n_copies = heads, n_experts = E) (:375) and compute_moe(x, sel) (:383-388)."""
+    get_moe = _import_reference()
+    heads, E, K, Din, Dout, B, N = 4, 4, 2, 32, 16, 2, 24
+    args = make_args(moe_name="smoe_perturbed")
+    torch.manual_seed(31)
+    std = 0.3
+    layer = get_moe("smoe_perturbed")(n_experts=E * heads, dmodel=Din, out_dmodel=Dout * heads, n_heads=heads, topk=K, expert_size=1,
+                                      args=args, is_att=True, std=std, inp_expert=Din, out_expert=Dout, selection_dropout=0.0,
+                                      expert_dropout=0.0, std_gate=std, std_expert=std)
+    layer.train()
+    g = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        layer.expert_embeddings.copy_(torch.randn(layer.expert_embeddings.shape, generator=g))
+    x = torch.randn(B, N, Din, generator=g)
+    dy = torch.randn(B, N, heads, Dout, generator=g)
+    fx = {"meta": dict(bf16=bf16, heads=heads, E=E, K=K, Din=Din, Dout=Dout, B=B, N=N, std=std, args=vars(args),
+                       cvmm=ref_env.CVMM_META),
+          "state": {k: v.clone() for k, v in layer.state_dict().items()}, "x": x.clone(), "dy": dy.clone()}
+    xg = x.clone().requires_grad_(True)
+    up = {}
+    with amp(bf16, up):
+        sel = layer.att_forward(xg, n_copies=heads, n_experts=E)
+        out = layer.compute_moe(xg, sel)
+    (out.float() * dy).sum().backward()
+    fx["meta"]["autocast_fp32_upcasts"] = up
+    fx["sel_val"], fx["sel_index"], fx["gate_logits"] = sel.sel_val.detach().clone(), sel.raw_sel_index.clone(), sel.raw_sel.detach().clone()
+    fx["output"], fx["x_grad"] = out.detach().clone(), xg.grad.clone()
+    fx["grads"] = {k: (p.grad.clone() if p.grad is not None else None) for k, p in layer.named_parameters()}
+    tag = "bf16" if bf16 else "fp32"
+    torch.save(fx, os.path.join(HERE, f"pretrain_att_proj_{tag}.pt"))
+    print(f"wrote pretrain_att_proj_{tag}.pt", tuple(out.shape), out.dtype, {k: (None if v is None else tuple(v.shape)) for k, v in fx["grads"].items()})
+
+
 def schedule_case():
     get_moe = _import_reference()
     args = make_args(moe_name="competesmoe", stop_after=40, warm_up=0.25, rate_flip=0.6, max_compete_in_iter=2)
@@ -199,6 +238,9 @@ def main():
     run_case("competesmoe_comp_tribrid_fp32", "competesmoe", False, competition=True, args_kw=dict(tribrid=True))
     # BASELINE config 1: D=256, E=8, K=2, F=128, T=1024 as [4,256] -- checksums only
     run_case("config1_smoe_fp32", "smoe", False, B=4, N=256, D=256, E=8, F_=128, K=2, full=False)
+    for bf16, tag in ((False, "fp32"), (True, "bf16")):
+        run_case(f"smoe_perturbed_{tag}", "smoe_perturbed", bf16)
+        attention_projection_case(bf16)
     cvmm_index_case()
     cvmm_kernel_case(False)
     cvmm_kernel_case(True)

@@ -153,7 +153,7 @@ def import_reference():
     lay.cvmm = cv.cvmm
     lay.cvmm_prepare_sel = cv.cvmm_prepare_sel
     _pkg("layers.moe", os.path.join(REF, "layers", "moe"))
-    for m in ("register", "moe", "smoe", "competesmoe", "deepseekv2", "deepseekv3"):
+    for m in ("register", "moe", "smoe", "competesmoe", "deepseekv2", "deepseekv3", "smoe_perturbed"):
         importlib.import_module(f"layers.moe.{m}")
     return sys.modules["layers.moe.register"].get_moe
 

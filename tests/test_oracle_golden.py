@@ -345,3 +345,57 @@ def test_cvmm_restatement_against_the_reference_kernels(tag):
     (out.float() * fx["dy"]).sum().backward()
     for name, t in (("x", x), ("keys", keys), ("values", values), ("w", w)):
         assert rel_l2(t.grad, fx["grads"][name]) <= r, (name, rel_l2(t.grad, fx["grads"][name]))
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_pretrain_smoe_perturbed(tag):
+    """smoe_perturbed FFN form (smoe_perturbed.py:162-197): cosine gate over renormalised expert embeddings, softmax(gate / T),
+    top-k of the softmax values re-normalised by a softmax; goldens from the reference class."""
+    fx = load(f"pretrain_smoe_perturbed_{tag}")
+    meta, st = fx["meta"], fx["state"]
+    op = torch.bfloat16 if meta["bf16"] else torch.float32
+    x = fx["x"].clone().requires_grad_(True)
+    keys, values, esel = (st[k].clone().requires_grad_(True) for k in ("keys", "values", "expert_sel"))
+    emb = O.renorm_embeddings(st["expert_embeddings"]).clone().requires_grad_(True)
+    lg = O.perturbed_gate(x, esel, emb, op if meta["bf16"] else None)
+    sm = torch.softmax((lg / 0.3).float(), -1).to(x.dtype)
+    w, idx = O.top_softmax(sm, meta["K"])
+    out = O.pretrain_ffn(x, idx, w, keys, values, "relu", op)
+    reg = O.entropy_balance(lg) * meta["args"]["balance_loss_coef"]
+    o2, g2 = out.detach().reshape(-1, out.shape[-1]).double(), fx["output"].reshape(-1, out.shape[-1]).double()
+    bad = (o2 - g2).norm(dim=-1) / (g2.norm(dim=-1) + 1e-12) > 5e-2      # exact ties of bf16 logits (torch.topk's pick is unspecified)
+    assert float(bad.float().mean()) <= (0.0 if tag == "fp32" else 0.03)
+    r = 1e-5 if tag == "fp32" else 2e-4
+    assert rel_l2(o2[~bad], g2[~bad]) <= r
+    assert abs(float(reg) - float(fx["reg_loss"]["mlp_ebalance"])) <= 1e-6
+    if not bool(bad.any()):
+        ((out.float() * fx["dy"]).sum() + reg.float()).backward()
+        assert rel_l2(x.grad, fx["x_grad"]) <= 4 * r
+        for k, p in (("keys", keys), ("values", values), ("expert_sel", esel), ("expert_embeddings", emb)):
+            assert rel_l2(p.grad, fx["grads"][k]) <= 4 * r, (k, rel_l2(p.grad, fx["grads"][k]))
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_moe_attention_projection(tag):
+    """att_forward + compute_moe of the layer built as FullMoeRelativeAttentionCore.create_param_block
+    builds it (is_att = True), golden from the reference running its own cvmm kernels."""
+    fx = load(f"pretrain_att_proj_{tag}")
+    meta, st = fx["meta"], fx["state"]
+    op = torch.bfloat16 if meta["bf16"] else torch.float32
+    x = fx["x"].clone().requires_grad_(True)
+    experts, esel = (st[k].clone().requires_grad_(True) for k in ("experts", "expert_sel"))
+    emb = O.renorm_embeddings(st["expert_embeddings"]).clone().requires_grad_(True)
+    out, val, index, logits = O.attention_projection(x, esel, emb, experts, meta["heads"], meta["E"], meta["K"], op)
+    same = (index.sort(-1).values == fx["sel_index"].sort(-1).values).all(-1)          # [B, N, heads]
+    assert float((~same).float().mean()) <= (0.0 if tag == "fp32" else 0.03)
+    out, val, index, logits = O.attention_projection(x, esel, emb, experts, meta["heads"], meta["E"], meta["K"], op,
+                                                     forced_index=fx["sel_index"])
+    r = 1e-5 if tag == "fp32" else 2e-4
+    assert rel_l2(logits, fx["gate_logits"]) <= r
+    assert rel_l2(val, fx["sel_val"]) <= r
+    assert out.shape == fx["output"].shape and out.dtype == fx["output"].dtype
+    assert rel_l2(out, fx["output"]) <= r, rel_l2(out, fx["output"])
+    (out.float() * fx["dy"]).sum().backward()
+    assert rel_l2(x.grad, fx["x_grad"]) <= 4 * r
+    for k, p in (("experts", experts), ("expert_sel", esel), ("expert_embeddings", emb)):
+        assert rel_l2(p.grad, fx["grads"][k]) <= 4 * r, (k, rel_l2(p.grad, fx["grads"][k]))

@@ -109,6 +109,50 @@ def test_pretrain_competesmoe_option_flags_match_golden(case):
     test_pretrain_layer_matches_golden(case, "fp32")
 
 
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_smoe_perturbed_matches_golden(tag, monkeypatch):
+    """`smoe_perturbed` FFN form (cosine gate over renormalised expert embeddings, smoe_perturbed.py:148-197) against the reference
+    class.  Its bf16 logits are cosines in [-1.5, 1.5]: exact ties are more frequent than for the linear gates."""
+    import tests.test_pretrain_modules_gpu as me
+    monkeypatch.setattr(me, "BF16_BAD_ROWS", 0.04)
+    test_pretrain_layer_matches_golden("smoe_perturbed", tag)
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_moe_attention_projection_matches_golden(tag):
+    """the MoE attention projection -- the layer built with is_att=True exactly as
+    FullMoeRelativeAttentionCore.create_param_block does (full_moe_relative_attention.py:267-300), then att_forward (:375) and
+    compute_moe (:383-388) -- against the reference running its own Triton cvmm kernels."""
+    fx = load(f"pretrain_att_proj_{tag}")
+    m = fx["meta"]
+    bf16 = m["bf16"]
+    heads, E, K = m["heads"], m["E"], m["K"]
+    layer = get_moe("smoe_perturbed")(n_experts=E * heads, dmodel=m["Din"], out_dmodel=m["Dout"] * heads, n_heads=heads, topk=K,
+                                      expert_size=1, args=types.SimpleNamespace(**m["args"]), is_att=True, std=m["std"],
+                                      inp_expert=m["Din"], out_expert=m["Dout"], selection_dropout=0.0, expert_dropout=0.0,
+                                      std_gate=m["std"], std_expert=m["std"])
+    layer.load_state_dict(fx["state"], strict=True)
+    layer = layer.to(DEV).train()
+    x = fx["x"].to(DEV).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        sel = layer.att_forward(x, n_copies=heads, n_experts=E)
+        out = layer.compute_moe(x, sel)
+    assert out.shape == fx["output"].shape and out.dtype == fx["output"].dtype
+    same = (sel.raw_sel_index.cpu().long().sort(-1).values == fx["sel_index"].sort(-1).values).all(-1)      # [B, N, heads]
+    assert float((~same).float().mean()) <= (0.0 if not bf16 else 0.04)
+    assert rel_l2(sel.raw_sel.float().cpu(), fx["gate_logits"].float()) <= (1e-5 if not bf16 else 4e-3)
+    ok = same.to(DEV)
+    o, g = out.detach()[ok].double(), fx["output"].to(DEV)[ok].double()
+    assert rel_l2(o, g) <= (1e-5 if not bf16 else 2e-3), rel_l2(o, g)
+    (out.float() * fx["dy"].to(DEV)).sum().backward()
+    if bool(same.all()):
+        gt = 4e-5 if not bf16 else 8e-3
+        assert rel_l2(x.grad, fx["x_grad"].to(DEV)) <= gt
+        for name in ("experts", "expert_sel", "expert_embeddings"):
+            assert rel_l2(getattr(layer, name).grad, fx["grads"][name].to(DEV)) <= gt, name
+    assert layer.w_gate.grad is None            # the linear gate is allocated but unused by this layer, as upstream
+
+
 def test_config1_checksums():
     """BASELINE config 1 (D=256, E=8, K=2, F=128, T=1024 as [4,256]) against reference checksums."""
     fx = load("pretrain_config1_smoe_fp32")
