@@ -5,9 +5,14 @@ of 5-50 us each and the host cannot issue them fast enough: the step is launch-b
 the per-launch host cost.
 
 What makes a step capturable here (round-1's attempt died inside the capture; the causes, all host-side):
-  * the AccumulateGrad nodes of the parameters must live on the capture stream: warm-up iterations run on the SAME side stream
-    the capture uses (torch's whole-network recipe); with nodes created on the default stream the engine inserts a cross-stream
-    wait on the legacy stream inside the capture, HIP refuses it and the exception escapes on the autograd thread;
+  * the AccumulateGrad nodes of the parameters must live on the capture stream.  Found by bisection on the GPU (tools/graph_bisect.py,
+    tools/graph_bisect2.py; gpurun_out r2c): every kernel of the path, the whole forward and a fwd+bwd step capture and replay
+    cleanly -- UNLESS an eager step ran on the default stream first AND something kept its autograd graph alive.  `MoeLayer` did:
+    `log_metrics` held `route.w` / `route.softmax` with their grad_fn, so the parameters' AccumulateGrad nodes of that eager step
+    survived, the engine inserted a wait on the default stream inside the capture, and the HIP runtime segfaulted in
+    hipStreamEndCapture.  Fixed at the source (the metrics are stored detached); warm-up iterations run on the SAME side stream the
+    capture uses (torch's whole-network recipe), and GraphedStep refuses to capture -- with the reason -- if the warm-up still sees
+    a stale node (a caller holding last step's loss / outputs);
   * no pageable host-to-device copy inside the capture: per-expert pointer tables (`ops.ptr_array`), chunk / segment offset
     tables and the host copy of the competition schedule are built by the warm-up iterations and only LOOKED UP while capturing
     (`ops.ptr_array` raises a clear error if a capture would have to build one);
@@ -20,6 +25,7 @@ one graph per branch and pick on the host, as the schedule is known ahead (`prob
 """
 from __future__ import annotations
 
+import warnings
 from typing import Callable, Sequence
 
 import torch
@@ -40,11 +46,21 @@ class GraphedStep:
         self.static_inputs = [t.detach().clone().requires_grad_(t.requires_grad) for t in inputs]
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
+        stale = False
         with torch.cuda.stream(self.stream):
             for _ in range(max(1, warmup)):
                 self._zero()
-                self._run()
+                with warnings.catch_warnings(record=True) as seen:
+                    warnings.simplefilter("always")
+                    self._run()
+                stale = any("AccumulateGrad node's stream does not match" in str(w.message) for w in seen)
         torch.cuda.current_stream().wait_stream(self.stream)
+        if stale:
+            raise RuntimeError(
+                "competesmoe_amd.graphs: a parameter's AccumulateGrad node from an earlier step (created on another stream) is still "
+                "alive -- some tensor of that step with a grad_fn (its loss, outputs, logged metrics) is still referenced.  Capturing "
+                "now would make the autograd engine wait on that stream inside the capture, which the HIP runtime does not survive. "
+                "Drop those references (del loss / outputs) and build the GraphedStep again.")
         torch.cuda.synchronize()
         self._zero()
         self.graph = torch.cuda.CUDAGraph()

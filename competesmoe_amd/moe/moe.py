@@ -191,8 +191,11 @@ class MoeLayer(nn.Module):
         aux, bal, z = self.combine_loss(route.idx, route.softmax, route.logits)
         infor = {"balance_loss": bal.clone().detach(), "router_z_loss": z.clone().detach()}
         if keep_metrics:
-            self.log_metrics.update(weights=route.w, balance_loss=infor["balance_loss"], router_z_loss=infor["router_z_loss"],
-                                    gate_softmax=route.softmax, selected_experts=route.idx)
+            # detached: a tensor with a grad_fn kept on the module keeps the WHOLE autograd graph of this step alive until the next
+            # forward -- its saved activations, and the parameters' AccumulateGrad nodes, which then carry a stale stream into a
+            # later hipGraph capture (the cause of round 1's capture crash, competesmoe_amd/graphs.py)
+            self.log_metrics.update(weights=route.w.detach(), balance_loss=infor["balance_loss"], router_z_loss=infor["router_z_loss"],
+                                    gate_softmax=route.softmax.detach(), selected_experts=route.idx)
         return aux, infor
 
     # ------------------------------------------------------------------ expert pointer table

@@ -107,26 +107,29 @@ def test_layer_matches_reference_golden(case, tag):
         if not fx["meta"]["competition"]:
             rows_ok = (live_idx.long() == gi).all(-1)
         else:
-            # competition: routing = top-K of the mean-softplus affinities, computed in x.dtype.  In bf16 those are
-            # 8-bit values with frequent (near-)ties: rows whose selection differs from the
-            # reference's must be within one bf16 ulp of a tie; they are excluded from the elementwise check.
+            # competition: routing = top-K of the mean-softplus affinities, computed in x.dtype.  The kernel's affinities are
+            # bit-identical to the reference's; bf16 affinities are 8-bit values with exact ties, and torch.topk's choice among equal
+            # values is unspecified (the kernel takes the lowest index) -- so a row may differ ONLY where the reference's own scores
+            # tie, and must then select equal values.  Observed: 6 of 128 rows differ as sets, all exact ties
+            # (profiles/r02/parity_report.txt); such rows are excluded from the elementwise output check.
             aw, aidx, asm, aff, _ = layer.competition_policy(fx["x"].to(DEV))
-            ga = fx["aff_scores"].to(DEV).reshape(-1, aff.shape[-1]).float()
-            assert max_rel(aff.reshape(ga.shape), ga) <= (1e-5 if dt == torch.float32 else 2 ** -7)
+            ga = fx["aff_scores"].to(DEV).reshape(-1, aff.shape[-1])
+            if dt == torch.float32:
+                assert max_rel(aff.reshape(ga.shape), ga) <= 1e-5
+            else:
+                assert torch.equal(aff.reshape(ga.shape), ga.to(aff.dtype)), "bf16 affinities must be bit-identical to the reference's"
+            ga = ga.float()
             gai = fx["aff_selected"].to(DEV).reshape(-1, K)
             rows_ok = (aidx.reshape(-1, K).long() == gai).all(-1)
             bad = ~rows_ok
             if dt == torch.float32:
                 assert not bad.any()
-            else:
-                # observed on every bf16 competition fixture: 6 of 128 rows = 0.047 (profiles/r02/parity_report.txt, identical with
-                # the precise and the fast softplus); bound = observed + one row
-                print(f"bf16 competition rows routed differently: {float(bad.float().mean()):.4f}")
-                assert bad.float().mean() <= 0.055, bad.float().mean()
-                if bad.any():
-                    a = torch.gather(ga, -1, aidx.reshape(-1, K).long())[bad].sort(-1).values
-                    b = torch.gather(ga, -1, gai)[bad].sort(-1).values
-                    assert ((a - b).abs() <= 2 ** -7 * b.abs()).all()
+            elif bad.any():
+                a = torch.gather(ga, -1, aidx.reshape(-1, K).long())[bad].sort(-1).values
+                b = torch.gather(ga, -1, gai)[bad].sort(-1).values
+                assert torch.equal(a, b), "a row routed differently from the reference without an exact tie in its scores"
+                print(f"bf16 competition rows whose top-K differs from the reference's (exact ties only): {float(bad.float().mean()):.4f}")
+                assert bad.float().mean() <= 0.10
     if not fx["meta"]["competition"]:
         assert int((~rows_ok).sum()) <= 2
     o = out.detach().reshape(-1, out.shape[-1])[rows_ok]
