@@ -27,6 +27,12 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
                  hipStream_t st);
 int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
               void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st, const int32_t* xcd_order = nullptr);
+int k_quantize_mxfp8(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, int transpose,
+                     void* q, void* s, hipStream_t st);
+int gg8f_rowspace(const void* Aq, int64_t lda, const void* As, int64_t ldas, const void* const* bq_ptrs, const void* const* bs_ptrs,
+                  int64_t ldb, int64_t ldbs, const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd,
+                  void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, const void* single_B,
+                  const void* single_BS, const void* single_bias, hipStream_t st);
 int k_router_select(const void*, int, int, int, int, int, int, float, float*, int32_t*, float*, hipStream_t);
 int k_router_select_bwd(const void*, int, int, int, int, int, int, float, const float*, const int32_t*, const float*, const float*,
                         const float*, void*, hipStream_t);
@@ -449,4 +455,63 @@ int csmoe_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slo
   CSMOE_CHECK_ARG(T == 0 || (dout && slot_of && dy), "combine_bwd_mixed: null pointer");
   CSMOE_CHECK_ARG((((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0, "combine_bwd_mixed: operands must be 16-byte aligned");
   return k_combine_bwd_mixed(dout, y, slot_of, w, dy, dw, T, K, D, (hipStream_t)stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------ MXFP8 path
+int csmoe_quantize_mxfp8(const void* x, const void* const* x_ptrs, int E, int64_t ldx, int R, int C, int dtype, int transpose,
+                         void* q, void* s, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && E >= 1 && R >= 0 && C >= 0, "quantize_mxfp8: bad arguments");
+  CSMOE_CHECK_ARG((x_ptrs != nullptr) || (x != nullptr && E == 1) || R == 0 || C == 0, "quantize_mxfp8: no input");
+  if (R == 0 || C == 0) return CSMOE_OK;
+  CSMOE_CHECK_ARG(q && s && ldx >= C, "quantize_mxfp8: null output or leading dimension too small");
+  const int es = dtype == CSMOE_BF16 ? 2 : 4;
+  if (transpose) {
+    if (R % 32 != 0) { csmoe_set_error("quantize_mxfp8: transposed form needs R %% 32 == 0 (R=%d)", R); return CSMOE_ERR_UNSUPPORTED; }
+  } else {
+    if (C % 32 != 0 || (ldx * es) % 16 != 0 || (x && ((uintptr_t)x & 15))) {
+      csmoe_set_error("quantize_mxfp8: needs C %% 32 == 0 and 16-byte aligned rows (C=%d ldx=%lld)", C, (long long)ldx);
+      return CSMOE_ERR_UNSUPPORTED;
+    }
+  }
+  return k_quantize_mxfp8(x_ptrs, x, E, ldx, R, C, dtype, transpose, q, s, (hipStream_t)stream);
+}
+
+static int fp8_shape_ok(int64_t lda, int64_t ldas, int64_t ldb, int64_t ldbs, int64_t ldc, int N, int Kd, const void* A, const void* C,
+                        const char* who) {
+  if (Kd % 128 != 0 || N % 8 != 0 || lda % 16 != 0 || ldb % 16 != 0 || ldas % 4 != 0 || ldbs % 4 != 0 || ldc % 8 != 0 ||
+      ((uintptr_t)A & 15) || ((uintptr_t)C & 15)) {
+    csmoe_set_error("%s: needs Kd %% 128 == 0, N %% 8 == 0, 16-byte aligned operands (N=%d Kd=%d)", who, N, Kd);
+    return CSMOE_ERR_UNSUPPORTED;
+  }
+  return CSMOE_OK;
+}
+
+int csmoe_grouped_gemm_mxfp8(const void* Aq, int64_t lda, const void* As, int64_t ldas, const void* const* bq_ptrs,
+                             const void* const* bs_ptrs, int64_t ldb, int64_t ldbs, const void* const* bias_ptrs,
+                             const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2, const void* aux, int64_t ldc,
+                             int epilogue, int act, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(E > 0 && M >= 0 && N > 0 && Kd > 0, "grouped_gemm_mxfp8: bad shape E=%d M=%d N=%d Kd=%d", E, M, N, Kd);
+  CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && act >= 0 && act <= 5, "grouped_gemm_mxfp8: bad epilogue/act");
+  CSMOE_CHECK_ARG(bq_ptrs && bs_ptrs && offsets && (M == 0 || (Aq && As && (C || (epilogue == CSMOE_EPI_BIAS_ACT && C2)))),
+                  "grouped_gemm_mxfp8: null pointer");
+  CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "grouped_gemm_mxfp8: ACTGRAD epilogue needs aux");
+  CSMOE_CHECK_ARG(lda >= Kd && ldb >= Kd && ldc >= N && ldas >= Kd / 32 && ldbs >= Kd / 32, "grouped_gemm_mxfp8: leading dimension too small");
+  if (M == 0) return CSMOE_OK;
+  if (int rc = fp8_shape_ok(lda, ldas, ldb, ldbs, ldc, N, Kd, Aq, C ? C : C2, "grouped_gemm_mxfp8")) return rc;
+  return gg8f_rowspace(Aq, lda, As, ldas, bq_ptrs, bs_ptrs, ldb, ldbs, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
+                       nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int csmoe_dense_gemm_mxfp8(const void* Aq, int64_t lda, const void* As, int64_t ldas, const void* Bq, const void* Bs, int64_t ldb,
+                           int64_t ldbs, const void* bias, int M, int N, int Kd, void* C, void* C2, const void* aux, int64_t ldc,
+                           int epilogue, int act, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(M >= 0 && N > 0 && Kd > 0, "dense_gemm_mxfp8: bad shape");
+  CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 3 && act >= 0 && act <= 5, "dense_gemm_mxfp8: bad epilogue/act");
+  CSMOE_CHECK_ARG(M == 0 || (Aq && As && Bq && Bs && (C || (epilogue == CSMOE_EPI_BIAS_ACT && C2))), "dense_gemm_mxfp8: null pointer");
+  CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "dense_gemm_mxfp8: ACTGRAD epilogue needs aux");
+  if (M == 0) return CSMOE_OK;
+  if (int rc = fp8_shape_ok(lda, ldas, ldb, ldbs, ldc, N, Kd, Aq, C ? C : C2, "dense_gemm_mxfp8")) return rc;
+  return gg8f_rowspace(Aq, lda, As, ldas, nullptr, nullptr, ldb, ldbs, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act,
+                       Bq, Bs, bias, (hipStream_t)stream);
 }

@@ -1,0 +1,143 @@
+// MXFP8 quantisation for the block-scaled MFMA path (BASELINE config 5): OCP e4m3 elements with one e8m0 scale per 32 elements
+// ALONG THE REDUCTION DIMENSION of the GEMM that will consume the tensor (OCP Microscaling spec: shared exponent =
+// floor(log2(amax)) - emax_elem, emax(e4m3) = 8; elements = round-to-nearest-even(x * 2^-shared), saturated at +-448).
+// The reference has no fp8: nothing upstream to cite; the oracle restates this file in torch.
+//   rows:       x [R, C] -> q [R, C] u8, s [R, C/32] u8          (blocks along the contiguous dim: activations, K-contiguous weights)
+//   transposed: x [R, C] -> q [C, R] u8, s [C, R/32] u8          (blocks along dim 0: the same weights for the transposed product)
+// Inputs bf16 or fp32 (the pretrain stack's fp32 master weights are quantised directly: no bf16 cast pass).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ int e8m0_of_amax(float amax) {
+  // biased exponent byte of 2^(floor(log2(amax)) - 8); amax == 0 (or subnormal) -> the smallest scale
+  const int be = (int)((__float_as_uint(amax) >> 23) & 0xff);      // floor(log2(amax)) + 127 for normal amax
+  const int s = be - 8;
+  return s < 0 ? 0 : (s > 254 ? 254 : s);
+}
+__device__ __forceinline__ float inv_scale_of(int sbyte) {         // 2^-(sbyte - 127), exact
+  const int e = 254 - sbyte;                                       // biased exponent of the reciprocal
+  return e <= 0 ? __uint_as_float(0x00400000u >> (-e)) : __uint_as_float((unsigned)e << 23);
+}
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+  c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+
+template <typename T> __device__ __forceinline__ void load32(const T* p, float (&v)[32]);
+template <> __device__ __forceinline__ void load32<bf16>(const bf16* p, float (&v)[32]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bf16x8 x = *(const bf16x8*)(p + 8 * c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[8 * c + j] = (float)x[j];
+  }
+}
+template <> __device__ __forceinline__ void load32<float>(const float* p, float (&v)[32]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const f32x4 x = *(const f32x4*)(p + 4 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[4 * c + j] = x[j];
+  }
+}
+
+// one lane per 32-element block; blocks of a row are consecutive lanes.  grid.y = matrix (expert) index
+template <typename T>
+__global__ void __launch_bounds__(256) quant_rows_kernel(const void* const* x_ptrs, const T* x_single, int64_t ldx, int R, int C,
+                                                         uint8_t* q, uint8_t* s, int64_t q_mat, int64_t s_mat) {
+  const int e = blockIdx.y;
+  const T* x = x_ptrs ? (const T*)x_ptrs[e] : x_single;
+  uint8_t* qe = q + (int64_t)e * q_mat;
+  uint8_t* se = s + (int64_t)e * s_mat;
+  const int nb = C >> 5;
+  const int64_t total = (int64_t)R * nb;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / nb), b = (int)(i - (int64_t)r * nb);
+    float v[32];
+    load32<T>(x + (int64_t)r * ldx + b * 32, v);
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    const int sb = e8m0_of_amax(amax);
+    const float inv = inv_scale_of(sb);
+    u32x4 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o0[j] = pack4_e4m3(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
+      o1[j] = pack4_e4m3(v[16 + 4 * j] * inv, v[17 + 4 * j] * inv, v[18 + 4 * j] * inv, v[19 + 4 * j] * inv);
+    }
+    uint8_t* dst = qe + (int64_t)r * C + b * 32;
+    *(u32x4*)dst = o0;
+    *(u32x4*)(dst + 16) = o1;
+    se[(int64_t)r * nb + b] = (uint8_t)sb;
+  }
+}
+
+// transposed: one wave per 32-row x 64-column tile; lane = column, the 32 rows of the block sit in the lane's registers
+template <typename T>
+__global__ void __launch_bounds__(256) quant_cols_kernel(const void* const* x_ptrs, const T* x_single, int64_t ldx, int R, int C,
+                                                         uint8_t* q, uint8_t* s, int64_t q_mat, int64_t s_mat) {
+  const int e = blockIdx.y;
+  const T* x = x_ptrs ? (const T*)x_ptrs[e] : x_single;
+  uint8_t* qe = q + (int64_t)e * q_mat;       // [C, R]
+  uint8_t* se = s + (int64_t)e * s_mat;       // [C, R/32]
+  const int lane = threadIdx.x & 63;
+  const int rb_n = R >> 5, cb_n = (C + 63) >> 6;
+  const int64_t tiles = (int64_t)rb_n * cb_n;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tiles; t += (int64_t)gridDim.x * 4) {
+    const int rb = (int)(t / cb_n), cb = (int)(t - (int64_t)rb * cb_n);
+    const int c = cb * 64 + lane;
+    if (c >= C) continue;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      v[i] = (float)x[(int64_t)(rb * 32 + i) * ldx + c];
+      amax = fmaxf(amax, fabsf(v[i]));
+    }
+    const int sb = e8m0_of_amax(amax);
+    const float inv = inv_scale_of(sb);
+    u32x4 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o0[j] = pack4_e4m3(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
+      o1[j] = pack4_e4m3(v[16 + 4 * j] * inv, v[17 + 4 * j] * inv, v[18 + 4 * j] * inv, v[19 + 4 * j] * inv);
+    }
+    uint8_t* dst = qe + (int64_t)c * R + rb * 32;
+    *(u32x4*)dst = o0;
+    *(u32x4*)(dst + 16) = o1;
+    se[(int64_t)c * rb_n + rb] = (uint8_t)sb;
+  }
+}
+
+}  // namespace
+
+int k_quantize_mxfp8(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, int transpose,
+                     void* q, void* s, hipStream_t st) {
+  if (E <= 0 || R <= 0 || C <= 0) return CSMOE_OK;
+  const int64_t q_mat = (int64_t)R * C;
+  const int64_t s_mat = transpose ? (int64_t)C * (R / 32) : (int64_t)R * (C / 32);
+  if (!transpose) {
+    const int64_t total = (int64_t)R * (C / 32);
+    dim3 grid((unsigned)std::min<int64_t>((total + 255) / 256, 8192), (unsigned)E), block(256);
+    if (in_dtype == CSMOE_BF16)
+      hipLaunchKernelGGL((quant_rows_kernel<bf16>), grid, block, 0, st, x_ptrs, (const bf16*)x_single, ldx, R, C, (uint8_t*)q, (uint8_t*)s, q_mat, s_mat);
+    else
+      hipLaunchKernelGGL((quant_rows_kernel<float>), grid, block, 0, st, x_ptrs, (const float*)x_single, ldx, R, C, (uint8_t*)q, (uint8_t*)s, q_mat, s_mat);
+  } else {
+    const int64_t tiles = (int64_t)(R / 32) * ((C + 63) / 64);
+    dim3 grid((unsigned)std::min<int64_t>((tiles + 3) / 4, 8192), (unsigned)E), block(256);
+    if (in_dtype == CSMOE_BF16)
+      hipLaunchKernelGGL((quant_cols_kernel<bf16>), grid, block, 0, st, x_ptrs, (const bf16*)x_single, ldx, R, C, (uint8_t*)q, (uint8_t*)s, q_mat, s_mat);
+    else
+      hipLaunchKernelGGL((quant_cols_kernel<float>), grid, block, 0, st, x_ptrs, (const float*)x_single, ldx, R, C, (uint8_t*)q, (uint8_t*)s, q_mat, s_mat);
+  }
+  CSMOE_CHECK_LAUNCH("quantize_mxfp8");
+  return CSMOE_OK;
+}

@@ -47,13 +47,18 @@ class GraphedStep:
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         stale = False
-        with torch.cuda.stream(self.stream):
-            for _ in range(max(1, warmup)):
-                self._zero()
-                with warnings.catch_warnings(record=True) as seen:
-                    warnings.simplefilter("always")
-                    self._run()
-                stale = any("AccumulateGrad node's stream does not match" in str(w.message) for w in seen)
+        warn_always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)          # the engine's stream-mismatch warning is a warn-ONCE: it must fire here even if it fired before
+        try:
+            with torch.cuda.stream(self.stream):
+                for _ in range(max(1, warmup)):
+                    self._zero()
+                    with warnings.catch_warnings(record=True) as seen:
+                        warnings.simplefilter("always")
+                        self._run()
+                    stale = any("AccumulateGrad node's stream does not match" in str(w.message) for w in seen)
+        finally:
+            torch.set_warn_always(warn_always)
         torch.cuda.current_stream().wait_stream(self.stream)
         if stale:
             raise RuntimeError(

@@ -253,6 +253,31 @@ int csmoe_softplus_mean(const void* y, void* aff, int R, int D, int dtype, int a
 int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype, int aff_dtype,
                             int precise, csmoe_stream_t stream);
 
+/* ---- MXFP8 expert GEMMs (BASELINE.json config 5: shared-expert variant on the fp8 matrix pipe) -------------------------
+ * The reference has no fp8 path: these entries have no upstream counterpart; the contract is the bf16 path's
+ * result within the quantisation error (tests: <= 3e-2 relative to the bf16 oracle, <= 2e-3 to the oracle's own MXFP8 emulation).
+ * Format: OCP e4m3 elements, one e8m0 scale (2^(s - 127)) per 32 consecutive elements ALONG THE REDUCTION dimension of the GEMM
+ * that consumes the tensor; scale = 2^(floor(log2(amax)) - 8), elements round-to-nearest-even, saturated at +-448.
+ *
+ * csmoe_quantize_mxfp8: E matrices [R, C] (x_ptrs[e], or the single matrix x when x_ptrs == null and E == 1), leading dimension
+ * ldx, dtype CSMOE_BF16 or CSMOE_F32 (fp32 master weights are quantised directly).  transpose == 0: q [E, R, C], s [E, R, C/32]
+ * (blocks along C; C % 32 == 0).  transpose != 0: q [E, C, R], s [E, C, R/32] (blocks along R; R % 32 == 0) -- the operand of the
+ * transposed product (dX = dY . W for a weight stored [N, K]). */
+int csmoe_quantize_mxfp8(const void* x, const void* const* x_ptrs, int E, int64_t ldx, int R, int C, int dtype, int transpose,
+                         void* q, void* s, csmoe_stream_t stream);
+/* Row-space grouped GEMM on v_mfma_scale_f32_16x16x128_f8f6f4: C[m, 0:N] = epilogue(sum_k A[m,k] B_e[n,k]) for the binned rows of
+ * expert e; A [M, Kd] e4m3 (lda) with scales [M, Kd/32] (ldas); B_e = bq_ptrs[e] [N, Kd] e4m3 (ldb), scales bs_ptrs[e] [N, Kd/32]
+ * (ldbs); bf16 outputs / bias / aux and the epilogues PLAIN / BIAS / BIAS_ACT / ACTGRAD of csmoe_grouped_gemm.
+ * Kd % 128 == 0, N % 8 == 0, 16-byte aligned operands, lda % 16 == 0, ldas % 4 == 0 (else CSMOE_ERR_UNSUPPORTED). */
+int csmoe_grouped_gemm_mxfp8(const void* Aq, int64_t lda, const void* As, int64_t ldas, const void* const* bq_ptrs,
+                             const void* const* bs_ptrs, int64_t ldb, int64_t ldbs, const void* const* bias_ptrs,
+                             const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2, const void* aux, int64_t ldc,
+                             int epilogue, int act, csmoe_stream_t stream);
+/* Dense form (one weight matrix: the always-on shared expert). */
+int csmoe_dense_gemm_mxfp8(const void* Aq, int64_t lda, const void* As, int64_t ldas, const void* Bq, const void* Bs, int64_t ldb,
+                           int64_t ldbs, const void* bias, int M, int N, int Kd, void* C, void* C2, const void* aux, int64_t ldc,
+                           int epilogue, int act, csmoe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
