@@ -540,3 +540,61 @@ def gate_bwd_dw(dlogits: torch.Tensor, x2: torch.Tensor, out_dtype) -> torch.Ten
     out = torch.empty(E * D, dtype=torch.float32, device=x2.device)
     L.check(lib.csmoe_dense_colsum(part.data_ptr(), E * D, nr, E * D, out.data_ptr(), L.F32, L.F32, _stream()), "gate_bwd_dw sum")
     return out.view(E, D).to(out_dtype)
+
+
+# ------------------------------------------------------------------------------------------------ MXFP8 (BASELINE config 5)
+def quantize_mxfp8(x: torch.Tensor, transpose: bool = False):
+    """x [R, C] or [E, R, C] (bf16 / fp32, contiguous) -> (q uint8, s uint8): e4m3 elements + e8m0 scales per 32 elements along C
+    (q [.., R, C], s [.., R, C/32]) or, transposed, along R (q [.., C, R], s [.., C, R/32]) -- csmoe_quantize_mxfp8."""
+    _need_cuda(x)
+    x = x.contiguous()
+    lead = x.shape[:-2]
+    R, C = x.shape[-2:]
+    E = 1
+    for d in lead:
+        E *= d
+    if transpose:
+        q = torch.empty(*lead, C, R, dtype=torch.uint8, device=x.device)
+        s = torch.empty(*lead, C, R // 32, dtype=torch.uint8, device=x.device)
+    else:
+        q = torch.empty(*lead, R, C, dtype=torch.uint8, device=x.device)
+        s = torch.empty(*lead, R, C // 32, dtype=torch.uint8, device=x.device)
+    ptrs = None if E == 1 else ptr_table(x, E, R * C * x.element_size())
+    nbytes = x.numel() * (x.element_size() + 1)
+    with _timed("quantize_mxfp8" + ("_t" if transpose else ""), nbytes):
+        L.check(lib.csmoe_quantize_mxfp8(x.data_ptr() if E == 1 else None, _ptr(ptrs), E, C, R, C, _dt(x), int(transpose),
+                                         q.data_ptr(), s.data_ptr(), _stream()), "quantize_mxfp8")
+    return q, s
+
+
+def grouped_gemm_mxfp8(Aq: torch.Tensor, As: torch.Tensor, Bq: torch.Tensor, Bs: torch.Tensor, offsets: torch.Tensor,
+                       bias_ptrs: Optional[torch.Tensor] = None, epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE,
+                       aux: Optional[torch.Tensor] = None, want_c2: bool = False, want_c: bool = True):
+    """Row-space grouped GEMM on the block-scaled fp8 MFMA: Aq [M, Kd] / As [M, Kd/32], Bq [E, N, Kd] / Bs [E, N, Kd/32] (uint8),
+    bf16 outputs [M, N] -- csmoe_grouped_gemm_mxfp8."""
+    M, Kd = Aq.shape
+    E, N, _ = Bq.shape
+    Cm = torch.empty(M, N, dtype=torch.bfloat16, device=Aq.device) if want_c else None
+    C2 = torch.empty(M, N, dtype=torch.bfloat16, device=Aq.device) if want_c2 else None
+    bq = ptr_table(Bq, E, N * Kd)
+    bs = ptr_table(Bs, E, N * (Kd // 32))
+    with _timed("grouped_gemm_mxfp8", 2.0 * M * N * Kd):
+        L.check(lib.csmoe_grouped_gemm_mxfp8(Aq.data_ptr(), Kd, As.data_ptr(), Kd // 32, bq.data_ptr(), bs.data_ptr(), Kd, Kd // 32,
+                                             _ptr(bias_ptrs), offsets.data_ptr(), E, M, N, Kd, _ptr(Cm), _ptr(C2), _ptr(aux), N,
+                                             epilogue, act, _stream()), "grouped_gemm_mxfp8")
+    return (Cm, C2) if want_c2 else Cm
+
+
+def dense_gemm_mxfp8(Aq: torch.Tensor, As: torch.Tensor, Bq: torch.Tensor, Bs: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                     epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE, aux: Optional[torch.Tensor] = None, want_c2: bool = False,
+                     want_c: bool = True):
+    """Dense form: Bq [N, Kd], Bs [N, Kd/32]."""
+    M, Kd = Aq.shape
+    N = Bq.shape[0]
+    Cm = torch.empty(M, N, dtype=torch.bfloat16, device=Aq.device) if want_c else None
+    C2 = torch.empty(M, N, dtype=torch.bfloat16, device=Aq.device) if want_c2 else None
+    with _timed("dense_gemm_mxfp8", 2.0 * M * N * Kd):
+        L.check(lib.csmoe_dense_gemm_mxfp8(Aq.data_ptr(), Kd, As.data_ptr(), Kd // 32, Bq.data_ptr(), Bs.data_ptr(), Kd, Kd // 32,
+                                           _ptr(bias), M, N, Kd, _ptr(Cm), _ptr(C2), _ptr(aux), N, epilogue, act, _stream()),
+                "dense_gemm_mxfp8")
+    return (Cm, C2) if want_c2 else Cm

@@ -1,0 +1,100 @@
+"""MXFP8 path (BASELINE config 5): quantisers and the block-scaled grouped GEMM against the oracle's emulation.
+
+No fp8 exists in the reference -> "parity unpinned" by upstream; the oracle restates the OCP
+Microscaling format in torch (oracle/mxfp8.py) and the tolerances are build-defined: bytes of the quantisers bit-exact; GEMM
+exact on exact data (small integers, power-of-two scales); <= 2e-3 relative L2 against the fp64 product of the DEQUANTISED
+operands; <= 3e-2 against the bf16 product of the unquantised ones."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+if torch.cuda.is_available():
+    from competesmoe_amd import ops, _lib as L
+
+from oracle import mxfp8 as MX
+from tests.golden_util import rel_l2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(64, 128), (300, 256), (3, 96, 160), (8, 128, 512)])
+def test_quantisers_match_the_emulation_bit_for_bit(shape, dtype):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * torch.exp(torch.randn(*shape[:-1], 1, generator=g) * 3)).to(dtype)
+    x[..., 0, :32] = 0                                  # an all-zero block
+    x[..., 1, 5] = 3.0e4                                # a block dominated by one large element (others underflow)
+    q, s = ops.quantize_mxfp8(x.to(DEV))
+    rq, rs = MX.quantize(x.float())
+    assert torch.equal(s.cpu(), rs) and torch.equal(q.cpu(), rq)
+    if shape[-2] % 32 == 0:
+        qt, st = ops.quantize_mxfp8(x.to(DEV), transpose=True)
+        rqt, rst = MX.quantize(x.float().transpose(-1, -2).contiguous())
+        assert torch.equal(st.cpu(), rst) and torch.equal(qt.cpu(), rqt)
+
+
+def _groups(E, M, seed):
+    g = torch.Generator().manual_seed(seed)
+    cuts = torch.sort(torch.randint(0, M + 1, (E - 1,), generator=g)).values
+    off = torch.cat([torch.zeros(1, dtype=torch.long), cuts, torch.tensor([M])])
+    if E > 2:
+        off[2] = off[1]
+    return off.int()
+
+
+@pytest.mark.parametrize("E,M,N,Kd", [(1, 40, 64, 128), (4, 700, 264, 256), (8, 3000, 512, 384), (3, 1000, 1024, 1024)])
+def test_gemm_is_exact_on_exact_data(E, M, N, Kd):
+    """Small integers (exactly representable in e4m3) and power-of-two block scales: every product and partial sum is exact in
+    fp32, so the kernel must equal the emulation bit for bit.  Asymmetric operands and per-block scales that differ between rows
+    and between k-blocks catch a swapped operand role, a wrong lane -> k-byte map and a wrong scale byte."""
+    g = torch.Generator().manual_seed(E * 1000 + N)
+    off = _groups(E, M, E + 1)
+    Aq = MX.to_e4m3_bytes(torch.randint(-2, 3, (M, Kd), generator=g).float())
+    Bq = MX.to_e4m3_bytes(torch.randint(-1, 3, (E, N, Kd), generator=g).float())
+    As = torch.randint(125, 130, (M, Kd // 32), generator=g, dtype=torch.uint8)
+    Bs = torch.randint(126, 129, (E, N, Kd // 32), generator=g, dtype=torch.uint8)
+    c = ops.grouped_gemm_mxfp8(Aq.to(DEV), As.to(DEV), Bq.to(DEV), Bs.to(DEV), off.to(DEV))
+    ref = MX.grouped_matmul(Aq, As, Bq, Bs, off).bfloat16()
+    assert torch.equal(c.cpu(), ref), float((c.cpu().float() - ref.float()).abs().max())
+
+
+@pytest.mark.parametrize("E,M,N,Kd", [(8, 2000, 512, 512), (16, 5000, 768, 1024)])
+def test_gemm_on_random_data_and_epilogues(E, M, N, Kd):
+    g = torch.Generator().manual_seed(M)
+    off = _groups(E, M, 3)
+    A = torch.randn(M, Kd, generator=g).bfloat16()
+    B = (torch.randn(E, N, Kd, generator=g) / math.sqrt(Kd)).bfloat16()
+    bias = (torch.randn(E, N, generator=g) * 0.5).bfloat16()
+    Aq, As = ops.quantize_mxfp8(A.to(DEV))
+    Bq, Bs = ops.quantize_mxfp8(B.to(DEV))
+    emu = MX.grouped_matmul(Aq.cpu(), As.cpu(), Bq.cpu(), Bs.cpu(), off)                    # fp64 product of the dequantised operands
+    full = torch.zeros(M, N, dtype=torch.float64)
+    for e in range(E):
+        r0, r1 = int(off[e]), int(off[e + 1])
+        full[r0:r1] = A[r0:r1].double() @ B[e].double().t()
+    c = ops.grouped_gemm_mxfp8(Aq, As, Bq, Bs, off.to(DEV))
+    assert rel_l2(c.cpu(), emu) <= 2e-3, rel_l2(c.cpu(), emu)
+    assert rel_l2(c.cpu(), full) <= 3e-2, rel_l2(c.cpu(), full)
+    bd = bias.to(DEV)
+    pre, act = ops.grouped_gemm_mxfp8(Aq, As, Bq, Bs, off.to(DEV), bias_ptrs=ops.ptr_table(bd, E, N * 2), epilogue=L.EPI_BIAS_ACT,
+                                      act=L.ACT_GELU, want_c2=True)
+    eb = emu.clone()
+    for e in range(E):
+        eb[int(off[e]):int(off[e + 1])] += bias[e].double()
+    assert rel_l2(pre.cpu(), eb) <= 2e-3
+    assert rel_l2(act.cpu(), torch.nn.functional.gelu(pre.cpu().double())) <= 3e-3
+    aux = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    dh = ops.grouped_gemm_mxfp8(Aq, As, Bq, Bs, off.to(DEV), epilogue=L.EPI_ACTGRAD, act=L.ACT_RELU, aux=aux)
+    assert rel_l2(dh.cpu(), emu.bfloat16().double() * (aux.cpu() > 0)) <= 2e-3
+    # dense (single matrix) form = the shared expert
+    d = ops.dense_gemm_mxfp8(Aq, As, Bq[0], Bs[0])
+    assert rel_l2(d.cpu(), MX.dequantize(Aq.cpu(), As.cpu()).double() @ MX.dequantize(Bq[0].cpu(), Bs[0].cpu()).double().t()) <= 2e-3
+
+
+def test_unsupported_shapes_raise():
+    A = torch.zeros(16, 96, dtype=torch.uint8, device=DEV)
+    with pytest.raises((ValueError, L.CsmoeError)):
+        ops.grouped_gemm_mxfp8(A, torch.zeros(16, 3, dtype=torch.uint8, device=DEV), torch.zeros(1, 64, 96, dtype=torch.uint8, device=DEV),
+                               torch.zeros(1, 64, 3, dtype=torch.uint8, device=DEV), torch.tensor([0, 16], dtype=torch.int32, device=DEV))
