@@ -622,3 +622,113 @@ class DiversityLoss(torch.autograd.Function):
         T, K, _ = y3.shape
         gs = (g.float() / float(T * K * K)).reshape(1).contiguous()
         return ops.pair_cosine_bwd(y3, gs).view(ctx.shape)
+
+
+# ======================================================================================================== MXFP8 experts
+class MoEFFNPackedFP8(torch.autograd.Function):
+    """MoEFFNPacked with the four row-space expert GEMMs of a step (GEMM 1, GEMM 2, dH, dXs) on the block-scaled fp8 matrix pipe
+    (BASELINE config 5; `csmoe_grouped_gemm_mxfp8`): operands quantised to MXFP8 (e4m3 + one e8m0 scale per 32 elements along each
+    GEMM's reduction dim), fp32 accumulation, bf16 results.  The weight gradients stay bf16 products of the bf16 activations
+    (`csmoe_grouped_wgrad`).  Master weights (fp32 or bf16) are quantised directly, once per use and orientation -- there is no
+    bf16 operand copy.  No counterpart upstream (the reference has no fp8): tolerance is build-defined, tests/test_fp8_gpu.py."""
+
+    @staticmethod
+    def forward(ctx, x2, w, idx, keys, values, bias, act: int, combine_mode: int):
+        x2 = x2.contiguous()
+        if x2.dtype != torch.bfloat16:
+            raise ValueError("competesmoe_amd: the fp8 expert path takes bf16 activations (run under bf16 autocast)")
+        E, D, F = keys.shape
+        T = x2.shape[0]
+        bins = ops.bin_tokens(idx, E)
+        xs = ops.dispatch_tokens(x2, bins)
+        xq, xsc = ops.quantize_mxfp8(xs)
+        kq, ks = ops.quantize_mxfp8(keys, transpose=True)                  # [E, F, D]: y = xs @ keys[e], reduction over D
+        b_op = b1 = None
+        if bias is not None:
+            b_op = bias.to(torch.bfloat16).contiguous()
+            b1 = ops.ptr_table(b_op, E, F * 2)
+        hpre, hact = ops.grouped_gemm_mxfp8(xq, xsc, kq, ks, bins.offsets, bias_ptrs=b1, epilogue=L.EPI_BIAS_ACT, act=act,
+                                            want_c2=True, want_c=act != L.ACT_RELU)
+        del xq, xsc, kq, ks
+        hq, hs = ops.quantize_mxfp8(hact)
+        vq, vs = ops.quantize_mxfp8(values, transpose=True)                # [E, Dout, F]: reduction over F
+        y = ops.grouped_gemm_mxfp8(hq, hs, vq, vs, bins.offsets)
+        out = ops.combine(y, bins, idx, w, combine_mode, T)
+        ctx.saved = (bins, xs, hpre, hact, y, b_op)
+        ctx.w, ctx.keys, ctx.values = w, keys, values
+        ctx.cfg = (act, None if bias is None else bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.saved is None:
+            raise RuntimeError("competesmoe_amd: saved activations were freed by the first backward pass; run the forward again")
+        bins, xs, hpre, hact, y, _ = ctx.saved
+        ctx.saved = None
+        act, bias_dtype = ctx.cfg
+        keys, values = ctx.keys, ctx.values
+        E, D, F = keys.shape
+        T = dout.shape[0]
+        need_dw = ctx.needs_input_grad[1]
+        dy, dw = ops.combine_bwd(dout.contiguous(), y if need_dw else None, bins, ctx.w, want_dw=need_dw, act_dtype=torch.bfloat16)
+        dyq, dys = ops.quantize_mxfp8(dy)
+        vq, vs = ops.quantize_mxfp8(values)                                # [E, F, Dout] as stored: dh = dy @ values[e]^T
+        dh = ops.grouped_gemm_mxfp8(dyq, dys, vq, vs, bins.offsets, epilogue=L.EPI_ACTGRAD, act=act,
+                                    aux=hpre if hpre is not None else hact)
+        del dyq, dys, vq, vs
+        gk = gv = gb = None
+        pd = keys.dtype
+        if ctx.needs_input_grad[4]:
+            gv = _grouped_wgrad(hact, dy, bins, E, pd)                     # [E, F, Dout]
+        if ctx.needs_input_grad[3]:
+            gk = _grouped_wgrad(xs, dh, bins, E, pd)                       # [E, D, F]
+        if bias_dtype is not None and ctx.needs_input_grad[5]:
+            gb = _grouped_colsum(dh, bins.offsets, E, bias_dtype)
+        dx2 = None
+        if ctx.needs_input_grad[0]:
+            dhq, dhs = ops.quantize_mxfp8(dh)
+            kq, ks = ops.quantize_mxfp8(keys)                              # [E, D, F] as stored: dxs = dh @ keys[e]^T
+            dxs = ops.grouped_gemm_mxfp8(dhq, dhs, kq, ks, bins.offsets)
+            dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
+        return dx2, dw, None, gk, gv, gb, None, None
+
+
+class DenseFFNFP8(torch.autograd.Function):
+    """The always-on shared expert on the same fp8 pipe: x [T, D] -> act(x @ w1 [D, Fs] (+ b1)) @ w2 [Fs, Dout] (packed layout of
+    the pretrain stack's `keys_shared[0]` / `values_shared[0]`, deepseekv2.py:97-105)."""
+
+    @staticmethod
+    def forward(ctx, x2, w1, b1, w2, act: int):
+        x2 = x2.contiguous()
+        xq, xsc = ops.quantize_mxfp8(x2)
+        w1q, w1s = ops.quantize_mxfp8(w1, transpose=True)                  # [Fs, D]
+        b1o = None if b1 is None else b1.to(torch.bfloat16).contiguous()
+        hpre, hact = ops.dense_gemm_mxfp8(xq, xsc, w1q, w1s, bias=b1o, epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True,
+                                          want_c=act != L.ACT_RELU)
+        hq, hs = ops.quantize_mxfp8(hact)
+        w2q, w2s = ops.quantize_mxfp8(w2, transpose=True)                  # [Dout, Fs]
+        y = ops.dense_gemm_mxfp8(hq, hs, w2q, w2s)
+        ctx.save_for_backward(x2, hpre, hact, w1, w2)
+        ctx.cfg = (act, None if b1 is None else b1.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, hpre, hact, w1, w2 = ctx.saved_tensors
+        act, b1_dtype = ctx.cfg
+        dy = dy.contiguous()
+        dyq, dys = ops.quantize_mxfp8(dy)
+        w2q, w2s = ops.quantize_mxfp8(w2)                                  # [Fs, Dout]
+        dh = ops.dense_gemm_mxfp8(dyq, dys, w2q, w2s, epilogue=L.EPI_ACTGRAD, act=act, aux=hpre if hpre is not None else hact)
+        gw1 = gb1 = gw2 = dx = None
+        if ctx.needs_input_grad[3]:
+            gw2 = _dense_wgrad(hact, dy, w2.dtype)                         # [Fs, Dout]
+        if ctx.needs_input_grad[1]:
+            gw1 = _dense_wgrad(x2, dh, w1.dtype)                           # [D, Fs]
+        if b1_dtype is not None and ctx.needs_input_grad[2]:
+            gb1 = _chunked_dense_colsum(dh, b1_dtype)
+        if ctx.needs_input_grad[0]:
+            dhq, dhs = ops.quantize_mxfp8(dh)
+            w1q, w1s = ops.quantize_mxfp8(w1)                              # [D, Fs]
+            dx = ops.dense_gemm_mxfp8(dhq, dhs, w1q, w1s)
+        return dx, gw1, gb1, gw2, None

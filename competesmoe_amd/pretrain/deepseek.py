@@ -16,7 +16,9 @@ class _SharedBase(MoE):
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         ws = kw.get("weight_scale", 1.0)
-        self.n_shared_experts = 1
+        # upstream hard-codes one shared expert (deepseekv2.py:97); `args.n_shared_experts` widens it to n x F (BASELINE config 5:
+        # 128 routed + 2 shared), which is how its own comment describes more than one
+        self.n_shared_experts = int(getattr(self.args, "n_shared_experts", 1))
         fs = self.expert_size * self.n_shared_experts
         self.values_shared = nn.Parameter(torch.empty(1, fs, self.v_dim))
         nn.init.normal_(self.values_shared, std=fs ** -0.5 * ws)

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from .. import ops
-from ..functional import DenseFFN, GateLogits, MoEFFNPacked, RouterSelect
+from ..functional import DenseFFN, DenseFFNFP8, GateLogits, MoEFFNPacked, MoEFFNPackedFP8, RouterSelect
 from .framework_layers import LoggingLayer, OncePerIterLayer, RegularizedLayer
 
 
@@ -78,6 +78,8 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         self.training = False            # the reference leaves the flag False until .train() (moe.py:104)
         self.num_experts = self.num_of_experts = n_experts
         self.real_n_experts = 1
+        # BASELINE config 5 (no counterpart upstream): the four row-space expert GEMMs of a step on the MXFP8 matrix pipe
+        self.fp8_experts = bool(getattr(args, "fp8_experts", False))
         self.selection_dropout = selection_dropout
         self.expert_dropout = expert_dropout
         self.sel_weight_scale = weight_scale
@@ -160,6 +162,15 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         wk = weights.reshape(-1, K)
         if op == torch.bfloat16:      # `reduction_weight.type_as(res) @ res` (cvmm.py:483, :499): the K weights enter as bf16 values
             wk = wk.to(op)
+        if self.fp8_experts:
+            if op != torch.bfloat16:
+                raise ValueError("competesmoe_amd: args.fp8_experts needs bf16 activations (bf16 autocast or a bf16 layer)")
+            out = MoEFFNPackedFP8.apply(x2, wk.float().contiguous(), selected_experts.reshape(-1, K).int().contiguous(),
+                                        self.keys if keys is None else keys, self.values if values is None else values,
+                                        self.bias if bias is None else bias, self.act_code, L.COMBINE_DOT)
+            if res is not None:
+                out = res + out.view(res.shape)
+            return out.view(*shp[:-1], -1)
         out = MoEFFNPacked.apply(x2, wk.float().contiguous(),
                                  selected_experts.reshape(-1, K).int().contiguous(),
                                  self.keys if keys is None else keys, self.values if values is None else values,
@@ -176,6 +187,9 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         shp = x.shape
         op = op_dtype(x)
         b = None if bias_shared is None else bias_shared[0]
+        if self.fp8_experts:
+            y = DenseFFNFP8.apply(x.reshape(-1, shp[-1]).to(op), keys_shared[0], b, values_shared[0], self.act_code)
+            return y.view(*shp[:-1], -1)
         y = DenseFFN.apply(x.reshape(-1, shp[-1]).to(op), keys_shared[0], b, values_shared[0], None, self.act_code, L.B_KN)
         return y.view(*shp[:-1], -1)
 
