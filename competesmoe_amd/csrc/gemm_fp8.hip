@@ -6,7 +6,10 @@
 // Structure = the 256x256, 8-wave, two-phase ("BAL") loop of gemm_bf16_v2.hip, byte for byte: a K-tile is 128 fp8 elements = the
 // same 128-byte image rows as 64 bf16, so the LDS-DMA fill, the source-side swizzle, the four image kinds (RL / RH / CL / CH), the
 // counted vmcnt discipline and the half-phase stagger carry over unchanged.  What differs:
-//   * a fragment is the 32 consecutive k-bytes of one row (lane l: row l & 15, bytes 32 (l >> 4) .. +31 = two 16-byte chunks);
+//   * a fragment is 32 k-bytes of one row in the instruction's own k order, measured with tools/probes/mfma_scale_probe.hip: lane l
+//     (row l & 15, group g = l >> 4) holds k = 16 g .. 16 g + 15 in its first four registers and k = 64 + 16 g .. + 15 in the last
+//     four -- the SAME two 16-byte chunks (g, g + 4) the bf16 kernel reads for its two K = 32 steps -- and the scale of the
+//     32-element block b (k = 32 b .. 32 b + 31) is taken from the lanes of group b;
 //   * one K = 128 MFMA per (column block, row block) and K-tile instead of two K = 32 ones: 16 per phase at 32 cycles each;
 //   * the e8m0 scales travel by LDS-DMA too (4 bytes per row and K-tile: one 256-byte wave-instruction per wave and K-tile --
 //     waves 0-3 the 256 row scales, waves 4-7 the 256 column scales), are read as bytes in phase A and handed to the MFMA as
@@ -86,8 +89,8 @@ __global__ void __launch_bounds__(512, 2) gg8f_kernel(Fp8Args p) {
   // ---------------- LDS read addressing ----------------
   const int g = lane >> 4, i16 = lane & 15;
   const int sw = (i16 >> 1) & 7;
-  const int f_lo = i16 * 128 + (((2 * g) ^ sw) << 4);          // chunk 2g   of this lane's row (source-side swizzle of dma_setup)
-  const int f_hi = i16 * 128 + (((2 * g + 1) ^ sw) << 4);      // chunk 2g+1
+  const int f_lo = i16 * 128 + ((g ^ sw) << 4);                // chunk g     of this lane's row (source-side swizzle of dma_setup)
+  const int f_hi = i16 * 128 + (((g + 4) ^ sw) << 4);          // chunk g + 4
   const int r_blk0 = wm * 4, c_blk0 = wn * 2;
 
   f32x4 acc[4][8];
