@@ -3,7 +3,9 @@
 No fp8 exists in the reference -> "parity unpinned" by upstream; the oracle restates the OCP
 Microscaling format in torch (oracle/mxfp8.py) and the tolerances are build-defined: bytes of the quantisers bit-exact; GEMM
 exact on exact data (small integers, power-of-two scales); <= 2e-3 relative L2 against the fp64 product of the DEQUANTISED
-operands; <= 3e-2 against the bf16 product of the unquantised ones."""
+operands; <= 6e-2 against the product of the unquantised ones -- the format's own error: e4m3 keeps 3 mantissa bits (RMS rounding
+error 2^-4 / sqrt(3) = 3.6 % per element, 5.1 % per product of two quantised operands) and independent errors of random-sign terms
+do not shrink relative to their sum (measured 4.2 % at K = 1024)."""
 import math
 
 import pytest
@@ -76,7 +78,7 @@ def test_gemm_on_random_data_and_epilogues(E, M, N, Kd):
         full[r0:r1] = A[r0:r1].double() @ B[e].double().t()
     c = ops.grouped_gemm_mxfp8(Aq, As, Bq, Bs, off.to(DEV))
     assert rel_l2(c.cpu(), emu) <= 2e-3, rel_l2(c.cpu(), emu)
-    assert rel_l2(c.cpu(), full) <= 3e-2, rel_l2(c.cpu(), full)
+    assert rel_l2(c.cpu(), full) <= 6e-2, rel_l2(c.cpu(), full)
     bd = bias.to(DEV)
     pre, act = ops.grouped_gemm_mxfp8(Aq, As, Bq, Bs, off.to(DEV), bias_ptrs=ops.ptr_table(bd, E, N * 2), epilogue=L.EPI_BIAS_ACT,
                                       act=L.ACT_GELU, want_c2=True)
@@ -98,3 +100,39 @@ def test_unsupported_shapes_raise():
     with pytest.raises((ValueError, L.CsmoeError)):
         ops.grouped_gemm_mxfp8(A, torch.zeros(16, 3, dtype=torch.uint8, device=DEV), torch.zeros(1, 64, 96, dtype=torch.uint8, device=DEV),
                                torch.zeros(1, 64, 3, dtype=torch.uint8, device=DEV), torch.tensor([0, 16], dtype=torch.int32, device=DEV))
+
+
+@pytest.mark.parametrize("name,K", [("smoe", 2), ("deepseekv2", 3)])
+def test_layer_on_the_fp8_pipe_tracks_the_bf16_layer(name, K):
+    """`args.fp8_experts` (BASELINE config 5; deepseekv2 with `n_shared_experts` = 2: routed experts + a shared expert of width 2F):
+    the same layer with GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 pipe against its bf16 HIP path (itself pinned to the reference):
+    outputs, input gradient and weight gradients within the format's error."""
+    import types
+    import torch.nn.functional as F
+    from competesmoe_amd.pretrain import get_moe
+    D, Fh, E, B, N = 256, 384, 8, 2, 192
+    mk = lambda fp8: types.SimpleNamespace(balance_loss_coef=0.01, fp8_experts=fp8, n_shared_experts=2, test_only=False)
+    torch.manual_seed(3)
+    ref = get_moe(name)(D, E, Fh, n_heads=K, activation=F.relu, log_interval=None, args=mk(False)).to(DEV).train()
+    lay = get_moe(name)(D, E, Fh, n_heads=K, activation=F.relu, log_interval=None, args=mk(True)).to(DEV).train()
+    lay.load_state_dict(ref.state_dict())
+    if name == "deepseekv2":
+        assert lay.keys_shared.shape == (1, D, 2 * Fh) and lay.values_shared.shape == (1, 2 * Fh, D)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, N, D, generator=g).to(DEV)
+    dy = torch.randn(B, N, D, generator=g).to(DEV)
+    res = []
+    for layer in (ref, lay):
+        layer.regularization_present = True
+        xg = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = layer(xg)
+            reg = sum(layer.get_reg_loss().values())
+        ((out.float() * dy).sum() + reg.float()).backward()
+        res.append((out.detach().float(), xg.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None}))
+    (o0, g0, p0), (o1, g1, p1) = res
+    assert rel_l2(o1, o0) <= 8e-2, rel_l2(o1, o0)
+    assert rel_l2(g1, g0) <= 1.2e-1, rel_l2(g1, g0)
+    assert set(p0) == set(p1)
+    for k in p0:
+        assert p1[k].dtype == p0[k].dtype and rel_l2(p1[k], p0[k]) <= 1.2e-1, (k, rel_l2(p1[k], p0[k]))
