@@ -29,24 +29,53 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0    # dense block-scaled fp8 peak, same guide
 HBM_PEAK_GBS = 8000.0
+ROUND = "r02"                    # profiles/<ROUND>/traffic.json holds the PMC pass of THIS round's kernels (see traffic_for)
+
+
+def kernel_sources_hash():
+    """sha1 over the HIP sources: ties a committed PMC traffic figure to the kernels it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "competesmoe_amd", "csrc", "*.h*"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_for(kernel):
+    """HBM-side bytes per launch of `kernel` from this round's committed rocprofv3 --pmc passes (PMC counters cannot be read from
+    inside this process), ONLY if they were collected on the kernels being timed now (matching source hash); else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", ROUND, "traffic.json")) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    if d.get("kernel_sources_sha1_16") != kernel_sources_hash():
+        return None, f"profiles/{ROUND}/traffic.json was collected on other kernel sources: not reported"
+    return d.get("bytes_per_launch", {}).get(kernel), d.get("note")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)       # BASELINE.md section 3: warm-up 10, measure >= 50 iterations
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tokens", type=int, default=32768)
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--d-model", type=int, default=4096)
     ap.add_argument("--d-ff", type=int, default=11008)
     ap.add_argument("--experts", type=int, default=64)
     ap.add_argument("--topk", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8: BASELINE config 5 -- the pretrain stack's deepseekv2 layer (routed experts + --shared shared experts) with "
+                         "GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 matrix pipe (fp32 master weights quantised directly, bf16 autocast)")
+    ap.add_argument("--shared", type=int, default=0, help="number of shared experts (width n x d_ff) of the deepseekv2 layer (fp8 / --stack pretrain)")
     ap.add_argument("--skew", action="store_true", help="add +2.0 to 8 gate rows (Zipf-like load, BASELINE.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=2048)
+    ap.add_argument("--cpu-tokens", type=int, default=4096)   # BASELINE.md section 4
     ap.add_argument("--competition", action="store_true", help="time the CompeteSMoE competition step (every expert dense + sparse recompute) instead of the sparse smoe step")
     ap.add_argument("--block", action="store_true", help="time the block around the layer, x + MoE(LayerNorm(x)) (SURVEY.md section 8 f1), with the fused LayerNorm+gate / residual-combine kernels")
     ap.add_argument("--block-unfused", action="store_true", help="same block composed from torch LayerNorm, the plain layer and a torch add (A/B for --block)")
@@ -98,9 +127,14 @@ def make_pretrain_layer(a, dev):
                                  balance_loss_coef=0.01, balance_loss_coef_comp=0.02, router_loss_coef=0.03, router_theta=0.5,
                                  in_topk=False, hybrid=False, tribrid=False, balance_affinity=False, is_cosine=False,
                                  is_norm_weight=False, norm_sigmoid=False, scale_weight=1.0, test_only=False)
+    name = "smoe"
+    if a.dtype == "fp8" or a.shared > 0:
+        name = "deepseekv2" if a.shared > 0 else "smoe"
+        args.fp8_experts = a.dtype == "fp8"
+        args.n_shared_experts = max(1, a.shared)
     with torch.device(dev):
-        layer = get_moe("smoe")(a.d_model, a.experts, a.d_ff, n_heads=a.topk, activation=F.relu, bias=False, log_interval=None,
-                                args=args)
+        layer = get_moe(name)(a.d_model, a.experts, a.d_ff, n_heads=a.topk, activation=F.relu, bias=False, log_interval=None,
+                              args=args)
     layer = layer.to(dev).train()
     layer.regularization_present = True
     return layer
@@ -125,9 +159,36 @@ def cpu_baseline(a):
     out, aux, _, _ = O.llava_smoe_forward(x, wg, experts, "gelu", K, args)
     torch.autograd.backward([out, aux], [dy, torch.ones(())])
     dt_s = time.perf_counter() - t0
-    return {"value": T / dt_s, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle (fp32 port of the reference SMoE layer), one fwd+bwd of {T} tokens, D={D} F={F} E={E} K={K}, "
-                      f"{dt_s:.1f} s"}
+    # BASELINE config 1 in full (the reference's own CPU-runnable case): pretrain-style layer D=256, E=8, K=2, F=128, 1024 tokens
+    D1, F1, E1, K1, T1 = 256, 128, 8, 2, 1024
+    g1 = torch.Generator().manual_seed(0)
+    x1 = torch.randn(4, 256, D1, generator=g1).requires_grad_(True)
+    k1 = (torch.randn(E1, D1, F1, generator=g1) * D1 ** -0.5).requires_grad_(True)
+    v1 = (torch.randn(E1, F1, D1, generator=g1) * (E1 * F1) ** -0.5).requires_grad_(True)
+    wg1 = (torch.randn(E1, D1, generator=g1) * D1 ** -0.5).requires_grad_(True)
+    best = None
+    for _ in range(3):
+        t1 = time.perf_counter()
+        lg = O.gate_logits(x1, wg1)
+        w1_, i1, _ = O.router_topk(lg, K1, x1.dtype)
+        o1 = O.pretrain_ffn(x1, i1, w1_, k1, v1, "relu", torch.float32)
+        (o1.sum() + O.entropy_balance(lg) * 0.01).backward()
+        d1 = time.perf_counter() - t1
+        best = d1 if best is None else min(best, d1)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": T / dt_s, "unit": "tokens/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+            "config1_tokens_per_s": round(T1 / best, 1),
+            "sample": f"CPU oracle (fp32 port of the reference SMoE layer) on {cores} threads of {cpu_model}: one fwd+bwd of {T} tokens, "
+                      f"D={D} F={F} E={E} K={K}, {dt_s:.1f} s; BASELINE config 1 in full (pretrain-style layer D=256 F=128 E=8 K=2, "
+                      f"1024 tokens): {best * 1e3:.1f} ms per fwd+bwd"}
 
 
 def main():
@@ -141,7 +202,9 @@ def main():
             sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if a.dtype == "fp8":
+        a.stack = "pretrain"
+    dt = torch.float32 if a.dtype == "fp32" else torch.bfloat16
     import torch.distributed as dist
     if world > 1 or a.force_ep:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -262,7 +325,8 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel family (grouped expert GEMM): FLOPs per launch / mean launch duration
-        gemm = {k: v for k, v in prof.items() if k.startswith("grouped_gemm") or k.startswith("grouped_wgrad") or k == "gate_wgrad"}
+        gemm = {k: v for k, v in prof.items() if k.startswith("grouped_gemm") or k.startswith("grouped_wgrad") or k == "gate_wgrad"
+                or k.startswith("dense_gemm_mxfp8")}
         detail = {}
         for k, v in prof.items():
             if k in gemm:
@@ -275,31 +339,28 @@ def main():
         if gemm:
             dom = max((k for k in gemm if k != "gate_wgrad"), key=lambda k: gemm[k]["ms"] * gemm[k]["calls"])
             ach = gemm[dom]["work"] / (gemm[dom]["ms"] * 1e-3) / 1e12
-            peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else 157.3
+            def peak_of(k):      # the matrix-pipe peak of the dtype THAT kernel computes in
+                if "mxfp8" in k:
+                    return MFMA_FP8_PEAK_TFLOPS
+                return 157.3 if a.dtype == "fp32" else MFMA_BF16_PEAK_TFLOPS
+            peak = peak_of(dom)
             big = {k: v for k, v in gemm.items() if k != "gate_wgrad"}
             tot_ms = sum(v["ms"] * v["calls"] for v in big.values()) / a.steps
             tot_fl = sum(v["work"] * v["calls"] for v in big.values()) / a.steps
-            # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value
-            # comes from the committed rocprofv3 --pmc passes of the same command (profiles/r01/traffic.json), null if absent
-            traffic = None
-            try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "traffic.json")) as fh:
-                    traffic = json.load(fh).get(dom)
-            except (OSError, ValueError):
-                pass
+            tot_peak_ms = sum(v["work"] * v["calls"] / (peak_of(k) * 1e12) for k, v in big.items()) / a.steps * 1e3
+            traffic, tnote = traffic_for(dom)
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic,
-                    "traffic_note": "bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01); algorithmic bytes of this launch: 7.75e9" if traffic and dom == "grouped_wgrad_tn" else None,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": tnote,
                     "all_grouped_gemm": {"ms_per_step": round(tot_ms, 3), "TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
-                                         "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4)},
+                                         "frac": round(tot_peak_ms / tot_ms, 4)},
                     "hbm_kernels": {k: {"GB/s": d["GB/s"], "frac": round(d["GB/s"] / HBM_PEAK_GBS, 4)}
                                     for k, d in detail.items() if "GB/s" in d}}
         res = {
-            "metric": "MoE-layer fwd+bwd tokens/sec at d_model=4096, 64 experts top-2", "value": round(total_tokens * a.steps / el, 1),
+            "metric": f"MoE-layer fwd+bwd tokens/sec at d_model={D}, {a.experts} experts top-{a.topk}", "value": round(total_tokens * a.steps / el, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": ("pretrain-stack layer (packed fp32 master weights, ReLU, no bias, bf16 autocast; weights cast to bf16 every step): " if a.stack == "pretrain" else "") + ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
-                                   f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, Linear+bias/GELU experts, "
+            "config": {"workload": ((f"BASELINE config 5: pretrain-stack deepseekv2 layer, {a.experts} routed + {a.shared} shared experts, GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 matrix pipe (fp32 master weights quantised directly, bf16 weight gradients): " if a.dtype == "fp8" else "pretrain-stack layer (packed fp32 master weights, ReLU, no bias, bf16 autocast; weights cast to bf16 every step): ") if a.stack == "pretrain" else "") + ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
+                                   f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, " + ("ReLU experts without bias, " if a.stack == "pretrain" else "Linear+bias/GELU experts, ") +
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
                        "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
                        "parallelism": "single GPU" if world == 1 else f"ep{world} (experts sharded, RCCL all-to-all)",
