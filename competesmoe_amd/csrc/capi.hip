@@ -29,6 +29,8 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
               void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st, const int32_t* xcd_order = nullptr);
 int k_quantize_mxfp8(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, int transpose,
                      void* q, void* s, hipStream_t st);
+int k_quantize_mxfp8_both(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, void* q,
+                          void* s, void* qt, void* st, hipStream_t stream);
 int gg8f_rowspace(const void* Aq, int64_t lda, const void* As, int64_t ldas, const void* const* bq_ptrs, const void* const* bs_ptrs,
                   int64_t ldb, int64_t ldbs, const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd,
                   void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, const void* single_B,
@@ -475,6 +477,19 @@ int csmoe_quantize_mxfp8(const void* x, const void* const* x_ptrs, int E, int64_
     }
   }
   return k_quantize_mxfp8(x_ptrs, x, E, ldx, R, C, dtype, transpose, q, s, (hipStream_t)stream);
+}
+
+int csmoe_quantize_mxfp8_both(const void* x, const void* const* x_ptrs, int E, int64_t ldx, int R, int C, int dtype, void* q, void* s,
+                              void* qt, void* st, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(dtype_ok(dtype) && E >= 1 && R >= 0 && C >= 0, "quantize_mxfp8_both: bad arguments");
+  CSMOE_CHECK_ARG((x_ptrs != nullptr) || (x != nullptr && E == 1) || R == 0 || C == 0, "quantize_mxfp8_both: no input");
+  if (R == 0 || C == 0) return CSMOE_OK;
+  CSMOE_CHECK_ARG(q && s && qt && st && ldx >= C, "quantize_mxfp8_both: null output or leading dimension too small");
+  if (R % 32 != 0 || C % 64 != 0) {
+    csmoe_set_error("quantize_mxfp8_both: needs R %% 32 == 0 and C %% 64 == 0 (R=%d C=%d)", R, C);
+    return CSMOE_ERR_UNSUPPORTED;
+  }
+  return k_quantize_mxfp8_both(x_ptrs, x, E, ldx, R, C, dtype, q, s, qt, st, (hipStream_t)stream);
 }
 
 static int fp8_shape_ok(int64_t lda, int64_t ldas, int64_t ldb, int64_t ldbs, int64_t ldc, int N, int Kd, const void* A, const void* C,

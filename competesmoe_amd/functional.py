@@ -642,7 +642,7 @@ class MoEFFNPackedFP8(torch.autograd.Function):
         bins = ops.bin_tokens(idx, E)
         xs = ops.dispatch_tokens(x2, bins)
         xq, xsc = ops.quantize_mxfp8(xs)
-        kq, ks = ops.quantize_mxfp8(keys, transpose=True)                  # [E, F, D]: y = xs @ keys[e], reduction over D
+        (kq_b, ks_b), (kq, ks) = ops.quantize_mxfp8_both(keys)             # backward pair [E, D, F]; forward pair [E, F, D] (reduction over D)
         b_op = b1 = None
         if bias is not None:
             b_op = bias.to(torch.bfloat16).contiguous()
@@ -651,10 +651,11 @@ class MoEFFNPackedFP8(torch.autograd.Function):
                                             want_c2=True, want_c=act != L.ACT_RELU)
         del xq, xsc, kq, ks
         hq, hs = ops.quantize_mxfp8(hact)
-        vq, vs = ops.quantize_mxfp8(values, transpose=True)                # [E, Dout, F]: reduction over F
+        (vq_b, vs_b), (vq, vs) = ops.quantize_mxfp8_both(values)           # backward pair [E, F, Dout]; forward pair [E, Dout, F]
         y = ops.grouped_gemm_mxfp8(hq, hs, vq, vs, bins.offsets)
         out = ops.combine(y, bins, idx, w, combine_mode, T)
         ctx.saved = (bins, xs, hpre, hact, y, b_op)
+        ctx.wq = (kq_b, ks_b, vq_b, vs_b)        # each master tensor is read ONCE per step: the backward's operands are kept
         ctx.w, ctx.keys, ctx.values = w, keys, values
         ctx.cfg = (act, None if bias is None else bias.dtype)
         return out
@@ -671,9 +672,10 @@ class MoEFFNPackedFP8(torch.autograd.Function):
         T = dout.shape[0]
         need_dw = ctx.needs_input_grad[1]
         dy, dw = ops.combine_bwd(dout.contiguous(), y if need_dw else None, bins, ctx.w, want_dw=need_dw, act_dtype=torch.bfloat16)
+        kq, ks, vq, vs = ctx.wq
+        ctx.wq = None
         dyq, dys = ops.quantize_mxfp8(dy)
-        vq, vs = ops.quantize_mxfp8(values)                                # [E, F, Dout] as stored: dh = dy @ values[e]^T
-        dh = ops.grouped_gemm_mxfp8(dyq, dys, vq, vs, bins.offsets, epilogue=L.EPI_ACTGRAD, act=act,
+        dh = ops.grouped_gemm_mxfp8(dyq, dys, vq, vs, bins.offsets, epilogue=L.EPI_ACTGRAD, act=act,                 # values as stored
                                     aux=hpre if hpre is not None else hact)
         del dyq, dys, vq, vs
         gk = gv = gb = None
@@ -687,8 +689,7 @@ class MoEFFNPackedFP8(torch.autograd.Function):
         dx2 = None
         if ctx.needs_input_grad[0]:
             dhq, dhs = ops.quantize_mxfp8(dh)
-            kq, ks = ops.quantize_mxfp8(keys)                              # [E, D, F] as stored: dxs = dh @ keys[e]^T
-            dxs = ops.grouped_gemm_mxfp8(dhq, dhs, kq, ks, bins.offsets)
+            dxs = ops.grouped_gemm_mxfp8(dhq, dhs, kq, ks, bins.offsets)   # keys as stored: dxs = dh @ keys[e]^T
             dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
         return dx2, dw, None, gk, gv, gb, None, None
 
@@ -701,24 +702,23 @@ class DenseFFNFP8(torch.autograd.Function):
     def forward(ctx, x2, w1, b1, w2, act: int):
         x2 = x2.contiguous()
         xq, xsc = ops.quantize_mxfp8(x2)
-        w1q, w1s = ops.quantize_mxfp8(w1, transpose=True)                  # [Fs, D]
+        (w1q_b, w1s_b), (w1q, w1s) = ops.quantize_mxfp8_both(w1)           # backward pair [D, Fs]; forward pair [Fs, D]
         b1o = None if b1 is None else b1.to(torch.bfloat16).contiguous()
         hpre, hact = ops.dense_gemm_mxfp8(xq, xsc, w1q, w1s, bias=b1o, epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True,
                                           want_c=act != L.ACT_RELU)
         hq, hs = ops.quantize_mxfp8(hact)
-        w2q, w2s = ops.quantize_mxfp8(w2, transpose=True)                  # [Dout, Fs]
+        (w2q_b, w2s_b), (w2q, w2s) = ops.quantize_mxfp8_both(w2)           # backward pair [Fs, Dout]; forward pair [Dout, Fs]
         y = ops.dense_gemm_mxfp8(hq, hs, w2q, w2s)
-        ctx.save_for_backward(x2, hpre, hact, w1, w2)
+        ctx.save_for_backward(x2, hpre, hact, w1, w2, w1q_b, w1s_b, w2q_b, w2s_b)
         ctx.cfg = (act, None if b1 is None else b1.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x2, hpre, hact, w1, w2 = ctx.saved_tensors
+        x2, hpre, hact, w1, w2, w1q, w1s, w2q, w2s = ctx.saved_tensors
         act, b1_dtype = ctx.cfg
         dy = dy.contiguous()
         dyq, dys = ops.quantize_mxfp8(dy)
-        w2q, w2s = ops.quantize_mxfp8(w2)                                  # [Fs, Dout]
         dh = ops.dense_gemm_mxfp8(dyq, dys, w2q, w2s, epilogue=L.EPI_ACTGRAD, act=act, aux=hpre if hpre is not None else hact)
         gw1 = gb1 = gw2 = dx = None
         if ctx.needs_input_grad[3]:
@@ -729,6 +729,5 @@ class DenseFFNFP8(torch.autograd.Function):
             gb1 = _chunked_dense_colsum(dh, b1_dtype)
         if ctx.needs_input_grad[0]:
             dhq, dhs = ops.quantize_mxfp8(dh)
-            w1q, w1s = ops.quantize_mxfp8(w1)                              # [D, Fs]
             dx = ops.dense_gemm_mxfp8(dhq, dhs, w1q, w1s)
         return dx, gw1, gb1, gw2, None

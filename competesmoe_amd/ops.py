@@ -567,6 +567,29 @@ def quantize_mxfp8(x: torch.Tensor, transpose: bool = False):
     return q, s
 
 
+def quantize_mxfp8_both(x: torch.Tensor):
+    """x [R, C] or [E, R, C] -> ((q, s), (qt, st)): both orientations of quantize_mxfp8 in one pass over x (weights: the forward
+    and the backward product reduce over different dims).  Falls back to two passes when C % 64 != 0."""
+    x = x.contiguous()
+    R, C = x.shape[-2:]
+    if R % 32 != 0 or C % 64 != 0:
+        return quantize_mxfp8(x), quantize_mxfp8(x, transpose=True)
+    lead = x.shape[:-2]
+    E = 1
+    for d in lead:
+        E *= d
+    dev = x.device
+    q = torch.empty(*lead, R, C, dtype=torch.uint8, device=dev)
+    s = torch.empty(*lead, R, C // 32, dtype=torch.uint8, device=dev)
+    qt = torch.empty(*lead, C, R, dtype=torch.uint8, device=dev)
+    st = torch.empty(*lead, C, R // 32, dtype=torch.uint8, device=dev)
+    ptrs = None if E == 1 else ptr_table(x, E, R * C * x.element_size())
+    with _timed("quantize_mxfp8_both", x.numel() * (x.element_size() + 2)):
+        L.check(lib.csmoe_quantize_mxfp8_both(x.data_ptr() if E == 1 else None, _ptr(ptrs), E, C, R, C, _dt(x), q.data_ptr(),
+                                              s.data_ptr(), qt.data_ptr(), st.data_ptr(), _stream()), "quantize_mxfp8_both")
+    return (q, s), (qt, st)
+
+
 def grouped_gemm_mxfp8(Aq: torch.Tensor, As: torch.Tensor, Bq: torch.Tensor, Bs: torch.Tensor, offsets: torch.Tensor,
                        bias_ptrs: Optional[torch.Tensor] = None, epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE,
                        aux: Optional[torch.Tensor] = None, want_c2: bool = False, want_c: bool = True):

@@ -265,6 +265,11 @@ int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add,
  * transposed product (dX = dY . W for a weight stored [N, K]). */
 int csmoe_quantize_mxfp8(const void* x, const void* const* x_ptrs, int E, int64_t ldx, int R, int C, int dtype, int transpose,
                          void* q, void* s, csmoe_stream_t stream);
+/* Both orientations in one pass over the source (weights are needed along one dim by the forward product and along the other by
+ * the backward product): q [E, R, C] / s [E, R, C/32] and qt [E, C, R] / st [E, C, R/32], bit-identical to the two separate calls.
+ * R % 32 == 0, C % 64 == 0. */
+int csmoe_quantize_mxfp8_both(const void* x, const void* const* x_ptrs, int E, int64_t ldx, int R, int C, int dtype, void* q, void* s,
+                              void* qt, void* st, csmoe_stream_t stream);
 /* Row-space grouped GEMM on v_mfma_scale_f32_16x16x128_f8f6f4: C[m, 0:N] = epilogue(sum_k A[m,k] B_e[n,k]) for the binned rows of
  * expert e; A [M, Kd] e4m3 (lda) with scales [M, Kd/32] (ldas); B_e = bq_ptrs[e] [N, Kd] e4m3 (ldb), scales bs_ptrs[e] [N, Kd/32]
  * (ldbs); bf16 outputs / bias / aux and the epilogues PLAIN / BIAS / BIAS_ACT / ACTGRAD of csmoe_grouped_gemm.

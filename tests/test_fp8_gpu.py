@@ -22,7 +22,7 @@ from tests.golden_util import rel_l2
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("shape", [(64, 128), (300, 256), (3, 96, 160), (8, 128, 512)])
+@pytest.mark.parametrize("shape", [(64, 128), (300, 256), (3, 96, 160), (8, 128, 512), (2, 64, 192)])
 def test_quantisers_match_the_emulation_bit_for_bit(shape, dtype):
     g = torch.Generator().manual_seed(sum(shape))
     x = (torch.randn(*shape, generator=g) * torch.exp(torch.randn(*shape[:-1], 1, generator=g) * 3)).to(dtype)
@@ -35,6 +35,8 @@ def test_quantisers_match_the_emulation_bit_for_bit(shape, dtype):
         qt, st = ops.quantize_mxfp8(x.to(DEV), transpose=True)
         rqt, rst = MX.quantize(x.float().transpose(-1, -2).contiguous())
         assert torch.equal(st.cpu(), rst) and torch.equal(qt.cpu(), rqt)
+        (q2, s2), (qt2, st2) = ops.quantize_mxfp8_both(x.to(DEV))          # one pass, both orientations: same bytes
+        assert torch.equal(q2, q) and torch.equal(s2, s) and torch.equal(qt2, qt) and torch.equal(st2, st)
 
 
 def _groups(E, M, seed):

@@ -3,11 +3,13 @@
 # bench command, then the per-launch summary.  usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>
 set -u
 TAG=${1:-v6}
+shift
+EXTRA="$*"          # extra bench.py flags (e.g. --dtype fp8 --experts 128 --shared 2)
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-python3 bench.py --steps 10 --warmup 3 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
+CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA"
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o t -- $CMD > $OUT/bench_${TAG}_under_rocprof.json 2> $OUT/kt.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o t -- $CMD > /dev/null 2> $OUT/pf.err || exit 1
@@ -18,7 +20,7 @@ find $OUT -name "*.csv" | head -20
 python3 tools/summarize_profile.py $(find $OUT/kt -name "*kernel_trace.csv") $OUT/bench_${TAG}_per_launch.txt \
   --fetch $(find $OUT/pf -name "*counter_collection.csv") --write $(find $OUT/pw -name "*counter_collection.csv") \
   --mfma $(find $OUT/pm -name "*counter_collection.csv") \
-  --title "round 1, build $TAG: rocprofv3 of \`python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline\` on MI355X" > /dev/null
+  --title "round ${ROUND:-2}, build $TAG: rocprofv3 of \`python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA\` on MI355X" > /dev/null
 cp $(find $OUT/kt -name "*kernel_stats.csv") $OUT/bench_${TAG}_kernel_stats.csv
 # the counter CSVs are large: keep the summaries only
 rm -rf $OUT/pf $OUT/pw $OUT/pm $OUT/kt/*/*kernel_trace.csv 2>/dev/null
