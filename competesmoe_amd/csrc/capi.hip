@@ -485,8 +485,9 @@ int csmoe_quantize_mxfp8_both(const void* x, const void* const* x_ptrs, int E, i
   CSMOE_CHECK_ARG((x_ptrs != nullptr) || (x != nullptr && E == 1) || R == 0 || C == 0, "quantize_mxfp8_both: no input");
   if (R == 0 || C == 0) return CSMOE_OK;
   CSMOE_CHECK_ARG(q && s && qt && st && ldx >= C, "quantize_mxfp8_both: null output or leading dimension too small");
-  if (R % 32 != 0 || C % 64 != 0) {
-    csmoe_set_error("quantize_mxfp8_both: needs R %% 32 == 0 and C %% 64 == 0 (R=%d C=%d)", R, C);
+  const int es2 = dtype == CSMOE_BF16 ? 2 : 4;
+  if (R % 32 != 0 || C % 32 != 0 || (ldx * es2) % 16 != 0 || (x && ((uintptr_t)x & 15))) {
+    csmoe_set_error("quantize_mxfp8_both: needs R %% 32 == 0, C %% 32 == 0 and 16-byte aligned rows (R=%d C=%d)", R, C);
     return CSMOE_ERR_UNSUPPORTED;
   }
   return k_quantize_mxfp8_both(x_ptrs, x, E, ldx, R, C, dtype, q, s, qt, st, (hipStream_t)stream);

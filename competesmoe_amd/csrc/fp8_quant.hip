@@ -7,6 +7,7 @@
 // Inputs bf16 or fp32 (the pretrain stack's fp32 master weights are quantised directly: no bf16 cast pass).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -117,71 +118,95 @@ __global__ void __launch_bounds__(256) quant_cols_kernel(const void* const* x_pt
 }
 
 // both orientations in ONE pass over the source (weights: the forward product needs blocks along one dim, the backward product
-// along the other; reading 4-byte masters twice was the larger half of the fp8 step's quantisation time): one wave per 32-row x
-// 64-column tile, lane = column.  Column blocks (32 rows) reduce inside the lane; row blocks (32 columns = half a wave) by a
-// 5-step butterfly; the row-major bytes go through 2 KiB of LDS so that both outputs leave as 16-byte stores.
+// along the other; reading 4-byte masters twice was the larger half of the fp8 step's quantisation time).  One 256-thread
+// workgroup per 32-row x 128-column tile: 16-byte global loads (512 B per row and wave-instruction) into an fp32 LDS tile, then
+// the 128 (row, 32-column block) pairs and the 128 columns (one 32-row block each) are quantised by one thread each straight from
+// LDS -- rows by ds_read_b128 along the row, columns by ds_read_b32 down the column (consecutive lanes = consecutive banks) -- and
+// every output leaves as 16-byte stores.  6 B of HBM traffic per element with fp32 masters (4 read + 2 written).
+constexpr int QB_R = 32, QB_C = 128, QB_LD = QB_C + 4;       // +4 floats: rows 16 B apart in bank space (b128 row reads)
+
 template <typename T>
 __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_ptrs, const T* x_single, int64_t ldx, int R, int C,
                                                          uint8_t* q, uint8_t* s, uint8_t* qt, uint8_t* st, int64_t q_mat,
                                                          int64_t s_mat, int64_t st_mat) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[4][32 * 64];
+  __shared__ __attribute__((aligned(16))) float tile[QB_R * QB_LD];
   const int e = blockIdx.y;
   const T* x = x_ptrs ? (const T*)x_ptrs[e] : x_single;
   uint8_t* qe = q + (int64_t)e * q_mat;         // [R, C]
   uint8_t* se = s + (int64_t)e * s_mat;         // [R, C/32]
   uint8_t* qte = qt + (int64_t)e * q_mat;       // [C, R]
   uint8_t* ste = st + (int64_t)e * st_mat;      // [C, R/32]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int rb_n = R >> 5, cb_n = C >> 6, nbc = C >> 5;
+  const int t = threadIdx.x;
+  const int rb_n = R / QB_R, cb_n = (C + QB_C - 1) / QB_C, nbc = C >> 5;
   const int64_t tiles = (int64_t)rb_n * cb_n;
-  uint8_t* my = stage[w];
-  for (int64_t t = (int64_t)blockIdx.x * 4 + w; t < tiles; t += (int64_t)gridDim.x * 4) {
-    const int rb = (int)(t / cb_n), cb = (int)(t - (int64_t)rb * cb_n);
-    const int c = cb * 64 + lane;
-    float v[32];
-    float cmax = 0.f;
+  for (int64_t ti = blockIdx.x; ti < tiles; ti += gridDim.x) {
+    const int rb = (int)(ti / cb_n), cb = (int)(ti - (int64_t)rb * cb_n);
+    const int r0 = rb * QB_R, c0 = cb * QB_C;
+    // ---- load: thread -> (row t / 32 + 8 i, 4 columns (t % 32) * 4)
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      v[i] = (float)x[(int64_t)(rb * 32 + i) * ldx + c];
-      cmax = fmaxf(cmax, fabsf(v[i]));
-    }
-    // ---- transposed output: this lane's column, blocks along the rows
-    {
-      const int sb = e8m0_of_amax(cmax);
-      const float inv = inv_scale_of(sb);
-      u32x4 o0, o1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o0[j] = pack4_e4m3(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
-        o1[j] = pack4_e4m3(v[16 + 4 * j] * inv, v[17 + 4 * j] * inv, v[18 + 4 * j] * inv, v[19 + 4 * j] * inv);
+    for (int i = 0; i < 4; ++i) {
+      const int r = (t >> 5) + 8 * i, c = (t & 31) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c0 + c < C) {
+        const T* src = x + (int64_t)(r0 + r) * ldx + c0 + c;
+        if constexpr (std::is_same<T, float>::value) {
+          v = *(const f32x4*)src;
+        } else {
+          const bf16x4 h = *(const bf16x4*)src;
+          v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
       }
-      uint8_t* dst = qte + (int64_t)c * R + rb * 32;
-      *(u32x4*)dst = o0;
-      *(u32x4*)(dst + 16) = o1;
-      ste[(int64_t)c * rb_n + rb] = (uint8_t)sb;
+      *(f32x4*)(tile + r * QB_LD + c) = v;
     }
-    // ---- row-major output: blocks along the columns = the two half-waves
+    __syncthreads();
+    if (t < 128) {
+      // ---- row-major output: pair (row t / 4, column block t % 4)
+      const int r = t >> 2, bk = t & 3;
+      if (c0 + bk * 32 < C) {
+        float v[32];
+        float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      float m = fabsf(v[i]);
+        for (int j = 0; j < 8; ++j) {
+          const f32x4 w4 = *(const f32x4*)(tile + r * QB_LD + bk * 32 + 4 * j);
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));      // max over the 32 lanes of this half
-      const int sb = e8m0_of_amax(m);
-      const float y = fminf(fmaxf(v[i] * inv_scale_of(sb), -448.f), 448.f);
-      const int wq = __builtin_amdgcn_cvt_pk_fp8_f32(y, 0.f, 0, false);
-      my[i * 64 + lane] = (uint8_t)(wq & 0xff);
-      if ((lane & 31) == 0) se[(int64_t)(rb * 32 + i) * nbc + cb * 2 + (lane >> 5)] = (uint8_t)sb;
+          for (int k = 0; k < 4; ++k) { v[4 * j + k] = w4[k]; amax = fmaxf(amax, fabsf(w4[k])); }
+        }
+        const int sb = e8m0_of_amax(amax);
+        const float inv = inv_scale_of(sb);
+        u32x4 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o0[j] = pack4_e4m3(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
+          o1[j] = pack4_e4m3(v[16 + 4 * j] * inv, v[17 + 4 * j] * inv, v[18 + 4 * j] * inv, v[19 + 4 * j] * inv);
+        }
+        uint8_t* dst = qe + (int64_t)(r0 + r) * C + c0 + bk * 32;
+        *(u32x4*)dst = o0;
+        *(u32x4*)(dst + 16) = o1;
+        se[(int64_t)(r0 + r) * nbc + (c0 >> 5) + bk] = (uint8_t)sb;
+      }
+    } else {
+      // ---- transposed output: column t - 128, its 32 rows
+      const int c = t - 128;
+      if (c0 + c < C) {
+        float v[32];
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { v[i] = tile[i * QB_LD + c]; amax = fmaxf(amax, fabsf(v[i])); }
+        const int sb = e8m0_of_amax(amax);
+        const float inv = inv_scale_of(sb);
+        u32x4 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o0[j] = pack4_e4m3(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
+          o1[j] = pack4_e4m3(v[16 + 4 * j] * inv, v[17 + 4 * j] * inv, v[18 + 4 * j] * inv, v[19 + 4 * j] * inv);
+        }
+        uint8_t* dst = qte + (int64_t)(c0 + c) * R + r0;
+        *(u32x4*)dst = o0;
+        *(u32x4*)(dst + 16) = o1;
+        ste[(int64_t)(c0 + c) * rb_n + rb] = (uint8_t)sb;
+      }
     }
-    __builtin_amdgcn_wave_barrier();
-    {
-      // 32 rows x 64 bytes: lane l stores row l / 2, half l & 1 (32 bytes)
-      const int r = lane >> 1, h = lane & 1;
-      const u32x4 a = *(const u32x4*)(my + r * 64 + h * 32), b = *(const u32x4*)(my + r * 64 + h * 32 + 16);
-      uint8_t* dst = qe + (int64_t)(rb * 32 + r) * C + cb * 64 + h * 32;
-      *(u32x4*)dst = a;
-      *(u32x4*)(dst + 16) = b;
-    }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
 }
 
@@ -190,8 +215,8 @@ __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_pt
 int k_quantize_mxfp8_both(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, void* q,
                           void* s, void* qt, void* st, hipStream_t stream) {
   if (E <= 0 || R <= 0 || C <= 0) return CSMOE_OK;
-  const int64_t tiles = (int64_t)(R / 32) * (C / 64);
-  dim3 grid((unsigned)std::min<int64_t>((tiles + 3) / 4, 8192), (unsigned)E), block(256);
+  const int64_t tiles = (int64_t)(R / QB_R) * ((C + QB_C - 1) / QB_C);
+  dim3 grid((unsigned)std::min<int64_t>(tiles, 16384), (unsigned)E), block(256);
   const int64_t q_mat = (int64_t)R * C, s_mat = (int64_t)R * (C / 32), st_mat = (int64_t)C * (R / 32);
   if (in_dtype == CSMOE_BF16)
     hipLaunchKernelGGL((quant_both_kernel<bf16>), grid, block, 0, stream, x_ptrs, (const bf16*)x_single, ldx, R, C, (uint8_t*)q,

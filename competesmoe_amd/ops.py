@@ -569,10 +569,10 @@ def quantize_mxfp8(x: torch.Tensor, transpose: bool = False):
 
 def quantize_mxfp8_both(x: torch.Tensor):
     """x [R, C] or [E, R, C] -> ((q, s), (qt, st)): both orientations of quantize_mxfp8 in one pass over x (weights: the forward
-    and the backward product reduce over different dims).  Falls back to two passes when C % 64 != 0."""
+    and the backward product reduce over different dims).  Falls back to two passes when R or C is not a multiple of 32."""
     x = x.contiguous()
     R, C = x.shape[-2:]
-    if R % 32 != 0 or C % 64 != 0:
+    if R % 32 != 0 or C % 32 != 0:
         return quantize_mxfp8(x), quantize_mxfp8(x, transpose=True)
     lead = x.shape[:-2]
     E = 1

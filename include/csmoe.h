@@ -267,7 +267,7 @@ int csmoe_quantize_mxfp8(const void* x, const void* const* x_ptrs, int E, int64_
                          void* q, void* s, csmoe_stream_t stream);
 /* Both orientations in one pass over the source (weights are needed along one dim by the forward product and along the other by
  * the backward product): q [E, R, C] / s [E, R, C/32] and qt [E, C, R] / st [E, C, R/32], bit-identical to the two separate calls.
- * R % 32 == 0, C % 64 == 0. */
+ * R % 32 == 0, C % 32 == 0, 16-byte aligned rows. */
 int csmoe_quantize_mxfp8_both(const void* x, const void* const* x_ptrs, int E, int64_t ldx, int R, int C, int dtype, void* q, void* s,
                               void* qt, void* st, csmoe_stream_t stream);
 /* Row-space grouped GEMM on v_mfma_scale_f32_16x16x128_f8f6f4: C[m, 0:N] = epilogue(sum_k A[m,k] B_e[n,k]) for the binned rows of
