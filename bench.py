@@ -34,13 +34,16 @@ HBM_PEAK_GBS = 8000.0
 ROUND = "r02"                    # profiles/<ROUND>/traffic.json holds the PMC pass of THIS round's kernels (see traffic_for)
 
 
+GEMM_SOURCES = ("gemm_bf16_v2.hip", "gemm_bf16_v2p.hip", "gemm_tiles.h", "common.h")    # the grouped-GEMM kernels the traffic is quoted for
+
+
 def kernel_sources_hash():
-    """sha1 over the HIP sources: ties a committed PMC traffic figure to the kernels it was measured on."""
-    import glob
+    """sha1 over the sources of the dominant (grouped GEMM) kernels: ties a committed PMC traffic figure to the kernels it was
+    measured on."""
     import hashlib
     h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(ROOT, "competesmoe_amd", "csrc", "*.h*"))):
-        with open(f, "rb") as fh:
+    for f in GEMM_SOURCES:
+        with open(os.path.join(ROOT, "competesmoe_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 

@@ -165,7 +165,10 @@ class EPFFN(torch.autograd.Function):
     """dispatch -> all-to-all -> local grouped FFN -> all-to-all -> combine, and the mirrored backward."""
 
     @staticmethod
-    def forward(ctx, x2, w, idx, tab: ExpertTable, E_global: int, group, combine_mode: int, *params):
+    def forward(ctx, x2, w, idx, tab: ExpertTable, E_global: int, group, combine_mode: int, want_slots: bool, *params):
+        """Returns (out [T, Dout], y_tk): the combined output and, with `want_slots`, the expert outputs per (token, k) slot in flat
+        order [T*K, Dout] -- what `torch.gather(expert_outputs, idx)` gives the single-GPU competition step for its diversity
+        loss (an empty tensor otherwise); gradients of both are accepted."""
         x2 = x2.contiguous()
         T = x2.shape[0]
         bins = ops.bin_tokens(idx, E_global)
@@ -182,10 +185,12 @@ class EPFFN(torch.autograd.Function):
         out = ops.combine(y, bins, idx, w, combine_mode, T)
         ctx.saved = (bins, lb, plan, rs, hpre, hact, y)
         ctx.tab, ctx.w, ctx.group, ctx.n_params = tab, w, group, len(params)
-        return out
+        ctx.want_slots = want_slots
+        y_tk = ops.dispatch_rows(y, _Unsort(bins)) if want_slots else y.new_empty(0)      # y_tk[t*K+k] = y[slot_of[t*K+k]]
+        return out, y_tk
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dy_tk=None):
         if ctx.saved is None:
             raise RuntimeError("competesmoe_amd: saved activations were freed by the first backward pass; a second backward "
                                "through the same graph (retain_graph=True) is not supported -- run the forward again")
@@ -196,11 +201,13 @@ class EPFFN(torch.autograd.Function):
         E, dev, pd = tab.E, dout.device, tab.param_dtype
         T = dout.shape[0]
         dy, dw = ops.combine_bwd(dout.contiguous(), y, bins, ctx.w, want_dw=ctx.needs_input_grad[1])
+        if dy_tk is not None and ctx.want_slots:               # gradient of the per-slot outputs (diversity loss), binned order
+            dy = dy + ops.dispatch_rows(dy_tk.contiguous(), ops.Bins(None, None, bins.perm, None, bins.n, bins.E, 1))
         dys = ops.dispatch_rows(a2a_rows(dy, plan.send_splits, plan.recv_splits, group), lb)
         dh = ops.grouped_gemm(dys, tab.w2_ptrs, L.B_KN, tab.F, tab.F, lb.offsets, E, epilogue=L.EPI_ACTGRAD, act=tab.act,
                               aux=hpre if hpre is not None else hact)
         pg = [None] * ctx.n_params
-        if any(ctx.needs_input_grad[7:]):
+        if any(ctx.needs_input_grad[8:]):
             es = torch.tensor([], dtype=pd).element_size()
 
             def table(buf):
@@ -226,7 +233,7 @@ class EPFFN(torch.autograd.Function):
             dxs_s = ops.grouped_gemm(dh, tab.w1_ptrs, L.B_KN, tab.D, tab.D, lb.offsets, E)
             dxs = a2a_rows(ops.dispatch_rows(dxs_s, _Unsort(lb)), plan.recv_splits, plan.send_splits, group)
             dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
-        return (dx2, dw, None, None, None, None, None, *pg)
+        return (dx2, dw, None, None, None, None, None, None, *pg)
 
 
 class EPFFNChunked(torch.autograd.Function):
@@ -392,7 +399,7 @@ class EPSMoeLayer(MoeLayer):
         if chunks > 1:
             out = EPFFNChunked.apply(x.reshape(B * N, D), w2, i2, tab, self.num_of_experts, self.group, L.COMBINE_SEQ, chunks, *params)
         else:
-            out = EPFFN.apply(x.reshape(B * N, D), w2, i2, tab, self.num_of_experts, self.group, L.COMBINE_SEQ, *params)
+            out, _ = EPFFN.apply(x.reshape(B * N, D), w2, i2, tab, self.num_of_experts, self.group, L.COMBINE_SEQ, False, *params)
         output = out.view(B, N, out.shape[-1])
         auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
         infor_aux = {}
@@ -400,4 +407,143 @@ class EPSMoeLayer(MoeLayer):
             # per-rank losses on local tokens, as data-parallel training of the reference computes them
             auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(selected_experts, gate_softmax, gate_logits)
             infor_aux = {"balance_loss": balance_loss.clone().detach(), "router_z_loss": router_z_loss.clone().detach()}
+        return output, auxiliary_loss, None, infor_aux
+
+
+# ------------------------------------------------------------------------------------------------ competition step under EP
+def _a2a_equal(t: torch.Tensor, group) -> torch.Tensor:
+    """all_to_all_single with equal splits along dim 0 (t [P * n, ...] -> [P * n, ...]: block p goes to rank p)."""
+    out = torch.empty_like(t)
+    dist.all_to_all_single(out, t.contiguous(), group=group)
+    return out
+
+
+class AllGatherRows(torch.autograd.Function):
+    """x [T, D] (same T on every rank) -> [P * T, D], rank-major.  Backward: every rank holds a partial gradient of ALL tokens (the
+    contribution of its local experts); block p goes to rank p and the P partial blocks are summed (an all-to-all + one add pass:
+    the bytes of a reduce-scatter, and it also runs on gloo)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        P = dist.get_world_size(group)
+        ctx.group, ctx.P = group, P
+        if P == 1:
+            return x.contiguous().clone()
+        outs = list(torch.empty(P, *x.shape, dtype=x.dtype, device=x.device).unbind(0))
+        dist.all_gather(outs, x.contiguous(), group=group)
+        return torch.cat(outs, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.P == 1:
+            return g, None
+        parts = _a2a_equal(g.contiguous(), ctx.group)                     # [P * T, D]: block s = rank s's partial gradient of MY tokens
+        return parts.view(ctx.P, -1, *g.shape[1:]).sum(0), None
+
+
+class ScatterAffinities(torch.autograd.Function):
+    """aff_local [P * T, El] -- the affinities of ALL tokens to MY experts -- -> [T, P * El]: the affinities of MY tokens to ALL
+    experts, columns in global expert order (rank p owns experts p * El ...).  Backward is the mirror exchange."""
+
+    @staticmethod
+    def forward(ctx, aff_local, group):
+        P = dist.get_world_size(group)
+        ctx.group, ctx.P = group, P
+        if P == 1:
+            return aff_local.contiguous().clone()
+        T, El = aff_local.shape[0] // P, aff_local.shape[1]
+        got = _a2a_equal(aff_local.contiguous(), group)                   # block s = rank s's experts' affinities of MY tokens
+        return got.view(P, T, El).permute(1, 0, 2).reshape(T, P * El).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.P == 1:
+            return g, None
+        P = ctx.P
+        T, E = g.shape
+        send = g.view(T, P, E // P).permute(1, 0, 2).reshape(P * T, E // P).contiguous()
+        return _a2a_equal(send, ctx.group), None
+
+
+@register_moe("competesmoe_ep")
+class EPCompeteSMoE(MoeLayer):
+    """`competesmoe` (moe_model/model/moe/competesmoe.py:8-415) with expert-parallel experts.  Router steps are the sparse exchange
+    of `smoe_ep`.  Competition steps: every rank gathers ALL ranks' tokens, runs ITS experts densely over them (DenseFFN kernels),
+    reduces each output row to its mean-softplus affinity (SoftplusMean) and sends every token's affinities back to the token's
+    owner, which then holds [T, E] affinities exactly as the single-GPU layer does; selection, losses and the sparse recompute of
+    the K winners (through the exchange) follow the single-GPU code.  The diversity loss takes the winners' outputs from the
+    sparse pass (they live on other ranks; same values as the dense outputs the single-GPU layer gathers from).
+    The reference has no expert parallelism: the contract is "the single-GPU layer's numbers on the same tokens"."""
+
+    def __init__(self, in_embed_dim=768, out_embed_dim=768, num_of_experts=4, num_selected=2, expert=None, args=None, group=None):
+        if not isinstance(expert, nn.ModuleList):
+            raise ValueError("EPCompeteSMoE: pass this rank's local experts as an nn.ModuleList")
+        super().__init__(in_embed_dim, out_embed_dim, num_of_experts, num_selected, expert, args)
+        from .moe.competesmoe import CompeteSMoE
+        self._single = CompeteSMoE                       # schedule + branch test are the single-GPU layer's, unbound
+        if args is None or not hasattr(args, "rate_flip") or not hasattr(args, "warm_up"):
+            raise ValueError("The 'args' parameter must have the attributes 'rate_flip' and 'warm_up'.")
+        self.group = group
+        self.warm_up, self.rate_flip = args.warm_up, args.rate_flip
+        self.total_steps, self.current_steps, self.step_warm, self.is_prob_flips = None, 0, None, True
+        self.register_buffer("prob_flips", torch.zeros(15801))
+        self._flips_host = self._flips_key = None
+        self.init_gate_weights()
+        reduce_grad_on_backward(self.gate.weight, group)
+
+    def set_total_steps(self, total_steps, id_layer, prob_flips_final):
+        return self._single.set_total_steps(self, total_steps, id_layer, prob_flips_final)      # rank 0 draws, broadcast
+
+    def set_current_steps(self, step):
+        self.current_steps = step
+
+    def _sparse(self, x, idx, w, mode, want_slots=False):
+        B, N, D = x.shape
+        tab, params = self._expert_table(len(self.experts), x.dtype, x.device)
+        K = idx.shape[-1]
+        out, y_tk = EPFFN.apply(x.reshape(B * N, D), w.reshape(B * N, K).float().contiguous(), idx.reshape(B * N, K).int().contiguous(),
+                                tab, self.num_of_experts, self.group, mode, want_slots, *params)
+        return out.view(B, N, -1), (y_tk.view(B, N, K, -1) if want_slots else None)
+
+    def competition_policy(self, x):
+        """[T, E] affinities of the local tokens to ALL experts, then the single-GPU selection (competesmoe.py:219-259)."""
+        from .functional import RouterSelect, SoftplusMean
+        B, N, D = x.shape
+        xa = AllGatherRows.apply(x.reshape(B * N, D), self.group)                   # [P*T, D]
+        outs = [self.dense_expert(i, xa.view(1, -1, D)) for i in range(len(self.experts))]
+        aff_local = torch.stack([SoftplusMean.apply(o.reshape(-1, o.shape[-1])) for o in outs], dim=-1)      # [P*T, El]
+        aff = ScatterAffinities.apply(aff_local, self.group)                        # [T, E]
+        scores = torch.sigmoid(aff) if getattr(self.args, "norm_sigmoid", False) else aff
+        if getattr(self.args, "norm_sigmoid", False):
+            asm = torch.softmax(aff, dim=-1, dtype=torch.float32)
+            _, idx, w = RouterSelect.apply(scores, self.num_selected, L.SEL_RAW, False)
+        else:
+            asm, idx, w = RouterSelect.apply(scores, self.num_selected, L.SEL_RAW, False)
+        E, K = self.num_of_experts, self.num_selected
+        return w.view(B, N, K), idx.view(B, N, K), asm.view(B, N, E), aff.view(B, N, E)
+
+    def forward(self, x, return_id_experts=False, is_vision=False):
+        import torch.nn.functional as F
+        gate_logits = self.gate_logits(x)
+        gate_w, gate_idx, gate_softmax = self.topk_expert(gate_logits=gate_logits)
+        auxiliary_loss, infor_aux = x.new_zeros(()), {}
+        if self._single._competing(self, x):
+            aff_w, aff_idx, aff_softmax, _ = self.competition_policy(x)
+            routerloss = F.mse_loss(gate_softmax, aff_softmax.detach())
+            if getattr(self.args, "hybrid", False):
+                il = aff_idx.long()
+                routerloss = routerloss + F.mse_loss(torch.gather(gate_softmax, -1, il), torch.gather(aff_softmax, -1, il).detach()) \
+                    * self.args.router_theta
+            output, topk_out = self._sparse(x, aff_idx, aff_w, L.COMBINE_SEQ_RW, want_slots=True)
+            diversity_loss = self.experts_diversity_loss(expert_outputs=topk_out)
+            balance_loss = self.balanceloss(selected_experts=aff_idx, gate_softmax=aff_softmax)
+            auxiliary_loss = (routerloss * self.args.router_loss_coef + diversity_loss * self.args.diversity_loss_coef
+                              + balance_loss * self.args.bal_comp_loss_coef)
+            infor_aux = {"balance_loss": balance_loss.clone().detach(), "diversity_loss": diversity_loss.clone().detach(),
+                         "routerloss": routerloss.clone().detach()}
+        else:
+            output, _ = self._sparse(x, gate_idx, gate_w, L.COMBINE_SEQ)
+            if x.requires_grad or return_id_experts:
+                auxiliary_loss, balance_loss, router_z_loss = self.combine_loss(gate_idx, gate_softmax, gate_logits)
+                infor_aux = {"balance_loss": balance_loss.clone().detach(), "router_z_loss": router_z_loss.clone().detach()}
         return output, auxiliary_loss, None, infor_aux

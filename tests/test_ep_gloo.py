@@ -123,3 +123,53 @@ def test_replicated_gate_gradient_with_two_micro_batches_gloo():
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+def _comp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from competesmoe_amd import ep
+        T, D, El = 6, 5, 3
+        E = El * world
+        xs = [torch.randn(T, D, generator=torch.Generator().manual_seed(40 + r)) for r in range(world)]
+        Ws = [torch.randn(D, generator=torch.Generator().manual_seed(90 + e)) for e in range(E)]       # stand-in "expert" e: <x, W_e>
+        x = xs[rank].clone().requires_grad_(True)
+        mine = [Ws[rank * El + i].clone().requires_grad_(True) for i in range(El)]
+        xa = ep.AllGatherRows.apply(x, None)                                         # [P*T, D]
+        ok = torch.equal(xa.detach(), torch.cat(xs))
+        aff_local = torch.stack([torch.tanh(xa @ w) for w in mine], dim=-1)          # [P*T, El]: all tokens x my experts
+        aff = ep.ScatterAffinities.apply(aff_local, None)                            # [T, E]: my tokens x all experts
+        want = torch.stack([torch.tanh(xs[rank] @ w) for w in Ws], dim=-1)
+        ok = ok and torch.allclose(aff.detach(), want, atol=1e-6)
+        coef = torch.arange(1, E + 1, dtype=torch.float32) * (rank + 1)              # a loss that differs per rank and per expert
+        (aff * coef).sum().backward()
+        # single-process expectation: total loss = sum_r sum_e coef_r[e] * tanh(<x_r, W_e>)
+        xr = [t.clone().requires_grad_(True) for t in xs]
+        wr = [w.clone().requires_grad_(True) for w in Ws]
+        tot = sum((torch.stack([torch.tanh(xr[r] @ w) for w in wr], -1) * (torch.arange(1, E + 1, dtype=torch.float32) * (r + 1))).sum()
+                  for r in range(world))
+        tot.backward()
+        ok = ok and torch.allclose(x.grad, xr[rank].grad, atol=1e-5)                # token gradients come home summed over the ranks' experts
+        for i in range(El):                                                          # expert gradients are complete on the owner
+            ok = ok and torch.allclose(mine[i].grad, wr[rank * El + i].grad, atol=1e-5)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_competition_exchanges_two_ranks_gloo():
+    """The two exchanges of the expert-parallel competition step (competesmoe_ep): gather every rank's tokens, scatter every token's
+    affinities back to its owner; values and both gradients against the single-process computation."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res == {0: True, 1: True}

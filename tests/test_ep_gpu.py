@@ -102,11 +102,87 @@ def _run(rank, world, port, backend, dt_name, q, chunks=1, empty_half=False):
         dist.destroy_process_group()
 
 
-def _launch(world, backend, dt_name, chunks=1, empty_half=False):
+def _run_comp(rank, world, port, backend, dt_name, q, *unused):
+    """competesmoe_ep on a competition step and on a router step against the single-GPU `competesmoe` on the same tokens."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from competesmoe_amd import ep
+        from competesmoe_amd.moe import get_moe
+        if backend == "gloo":          # two ranks on ONE device: RCCL refuses, the collectives go through host memory for this test
+            real_a2a, real_ag = dist.all_to_all_single, dist.all_gather
+
+            def a2a_host(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+                o = torch.empty(out.shape, dtype=out.dtype)
+                real_a2a(o, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+                out.copy_(o)
+
+            def ag_host(outs, inp, group=None):
+                hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+                real_ag(hs, inp.cpu(), group=group)
+                for o, h in zip(outs, hs):
+                    o.copy_(h)
+            dist.all_to_all_single, dist.all_gather = a2a_host, ag_host
+        dt = torch.float32 if dt_name == "fp32" else torch.bfloat16
+        B, N, D, F, E, K = 2, 64, 64, 128, 8, 2
+        args = types.SimpleNamespace(balance_loss_coef=0.01, router_z_loss_coef=0.001, rate_flip=1.0, warm_up=0.0, max_compete_in_iter=8,
+                                     router_loss_coef=0.03, diversity_loss_coef=0.02, bal_comp_loss_coef=0.01, hybrid=True,
+                                     router_theta=0.5, moe_name="competesmoe")
+        full = get_moe("competesmoe")(D, D, E, K, _experts(E, D, F, 7, dt, dev), args).to(dev).to(dt).train()
+        El = E // world
+        local = nn.ModuleList([_experts(E, D, F, 7, dt, dev)[rank * El + i] for i in range(El)])
+        epl = ep.EPCompeteSMoE(D, D, E, K, local, args).to(dev).to(dt).train()
+        ok = True
+        for competing in (True, False):
+            for lay in (full, epl):
+                lay.total_steps, lay.step_warm, lay.flip_steps = 8, 0, 8
+                lay.prob_flips = torch.full((8,), competing, dtype=torch.bool, device=dev)
+                lay._flips_host = None
+                lay.set_current_steps(2)
+                for p in lay.parameters():
+                    p.grad = None
+            g = torch.Generator().manual_seed(60 + rank)
+            x = torch.randn(B, N, D, generator=g).to(dt).to(dev)
+            dy = torch.randn(B, N, D, generator=g).to(dt).to(dev)
+            xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            oa, aa, _, ia = full(xa)
+            torch.autograd.backward([oa, aa.float()], [dy, torch.ones((), device=dev)])
+            ob, ab, _, ib = epl(xb)
+            torch.autograd.backward([ob, ab.float()], [dy, torch.ones((), device=dev)])
+            torch.cuda.synchronize()
+            tol = 2e-5 if dt == torch.float32 else 2e-2
+            rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+            ok = ok and torch.equal(oa, ob) and set(ia) == set(ib)
+            ok = ok and abs(float(aa) - float(ab)) <= 1e-5 * max(1.0, abs(float(aa))) * (1 if dt == torch.float32 else 100)
+            ok = ok and rel(xb.grad, xa.grad) <= tol
+            per = len(list(full.experts[0].parameters()))
+            refs = []
+            for e in range(E):
+                for p in full.experts[e].parameters():
+                    gsum = p.grad.detach().float().cpu()
+                    if world > 1:
+                        dist.all_reduce(gsum)
+                    refs.append(gsum)
+            mine = [p.grad.detach().float().cpu() for i in range(El) for p in epl.experts[i].parameters()]
+            for j, gm in enumerate(mine):
+                ok = ok and rel(gm, refs[rank * El * per + j]) <= tol
+            gg = full.gate.weight.grad.detach().float().cpu()
+            if world > 1:
+                dist.all_reduce(gg)
+            ok = ok and rel(epl.gate.weight.grad.cpu(), gg) <= tol
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _launch(world, backend, dt_name, chunks=1, empty_half=False, target=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, backend, dt_name, q, chunks, empty_half)) for r in range(world)]
+    procs = [ctx.Process(target=target or _run, args=(r, world, port, backend, dt_name, q, chunks, empty_half)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -123,6 +199,14 @@ def test_ep_world1_rccl_equals_single_gpu(dt_name):
 @pytest.mark.parametrize("dt_name", ["fp32", "bf16"])
 def test_ep_world2_one_gpu_equals_single_gpu(dt_name):
     assert _launch(2, "gloo", dt_name) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("world,backend,dt_name", [(1, "nccl", "fp32"), (1, "nccl", "bf16"), (2, "gloo", "fp32")])
+def test_competesmoe_ep_equals_single_gpu(world, backend, dt_name):
+    """`competesmoe_ep`: a competition step (gather tokens, dense local experts, scatter affinities, sparse recompute through the
+    exchange, diversity loss on the exchanged rows) and a router step give the single-GPU `competesmoe` layer's outputs bit for bit
+    and its losses / gradients within accumulation-order noise."""
+    assert _launch(world, backend, dt_name, target=_run_comp) == {r: True for r in range(world)}
 
 
 @pytest.mark.parametrize("chunks", [2, 3, 8])
