@@ -30,7 +30,8 @@
 // barrier A, so whichever group is ahead can neither re-fill a slot the other still reads nor read an image the other has not
 // finished fetching.  K-tiles past the end are still "issued": their offsets are out of range, the buffer descriptor turns
 // them into zero-fills of slots nobody reads, which keeps the wait counts uniform.
-// In-kernel s_memtime stamps of this loop (diagnostic build, profiles/r01/gemm_v2_stamps.txt): per phase ~450 cycles of
+// In-kernel s_memtime stamps of this loop (diagnostic build of round 1; its listing was not kept -- the persistent twin's is
+// profiles/r01/wgrad_stamps.txt): per phase ~450 cycles of
 // read/issue/wait, ~380 of MFMA and ~170 of release latency per barrier -- an LDS-DMA issue costs its wave 100-185 cycles.
 #include "gemm_tiles.h"
 #include <algorithm>
