@@ -27,6 +27,9 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
                  hipStream_t st);
 int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
               void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st, const int32_t* xcd_order = nullptr);
+int gg8c_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int64_t ldb, void* const* copy_ptrs,
+                  const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2, const void* aux,
+                  int64_t ldc, int epilogue, int act, const void* single_B, void* single_copy, const void* single_bias, hipStream_t st);
 int k_quantize_mxfp8(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, int transpose,
                      void* q, void* s, hipStream_t st);
 int k_quantize_mxfp8_both(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, void* q,
@@ -530,4 +533,27 @@ int csmoe_dense_gemm_mxfp8(const void* Aq, int64_t lda, const void* As, int64_t 
   if (int rc = fp8_shape_ok(lda, ldas, ldb, ldbs, ldc, N, Kd, Aq, C ? C : C2, "dense_gemm_mxfp8")) return rc;
   return gg8f_rowspace(Aq, lda, As, ldas, nullptr, nullptr, ldb, ldbs, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act,
                        Bq, Bs, bias, (hipStream_t)stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------ fp32 master weights in the GEMM
+int csmoe_grouped_gemm_f32w(const void* A, int64_t lda, const void* const* b_ptrs, int64_t ldb, void* const* b_copy_ptrs,
+                            const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                            const void* aux, int64_t ldc, int epilogue, int act, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(E > 0 && M >= 0 && N > 0 && Kd > 0, "grouped_gemm_f32w: bad shape E=%d M=%d N=%d Kd=%d", E, M, N, Kd);
+  CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 4 && act >= 0 && act <= 5, "grouped_gemm_f32w: bad epilogue/act");
+  CSMOE_CHECK_ARG(b_ptrs && offsets && (M == 0 || (A && (C || ((epilogue == CSMOE_EPI_BIAS_ACT || epilogue == CSMOE_EPI_ROUND_BIAS32_ACT) && C2)))),
+                  "grouped_gemm_f32w: null pointer");
+  CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "grouped_gemm_f32w: ACTGRAD epilogue needs aux");
+  CSMOE_CHECK_ARG(lda >= Kd && ldc >= N && ldb >= N, "grouped_gemm_f32w: leading dimension too small");
+  if (M == 0) return CSMOE_OK;
+  const void* Cany = C ? C : C2;
+  if (N % 8 || Kd % 8 || lda % 8 || ldb % 4 || ldc % 8 || ((uintptr_t)A & 15) || ((uintptr_t)Cany & 15) ||
+      (int64_t)M * lda * 2 >= 0x80000000ll || (int64_t)Kd * ldb * 4 >= 0x80000000ll) {
+    csmoe_set_error("grouped_gemm_f32w: needs N %% 8 == 0, Kd %% 8 == 0, 16-byte aligned rows and operands under 2 GiB each "
+                    "(N=%d Kd=%d); cast the weights and use csmoe_grouped_gemm", N, Kd);
+    return CSMOE_ERR_UNSUPPORTED;
+  }
+  return gg8c_rowspace(A, lda, b_ptrs, ldb, b_copy_ptrs, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act, nullptr,
+                       nullptr, nullptr, (hipStream_t)stream);
 }

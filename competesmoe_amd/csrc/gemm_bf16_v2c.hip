@@ -1,0 +1,358 @@
+// Row-space grouped GEMM whose weight operand is read straight from FP32 MASTERS: C[m, :] = epilogue(A[m, :] (bf16) x B_e) with
+// B_e [Kd, N] fp32 (the pretrain stack's `keys [E, D, F]` / `values [E, F, D]` under bf16 autocast).  The reference's Triton kernel
+// converts its operand tiles in registers (`a.to(tl.bfloat16)`, moe_pretrain_model/layers/cvmm.py:126-140); round 1 cast the whole
+// tensors to bf16 first, an HBM-bound pass of ~6 ms per step at the headline shape (34.5 GB).  Here the cast is part of the tile fill:
+//
+//   * same 256x256 tile, 8 waves, two phases per K-tile and half-phase stagger as the WIDE loop of gemm_bf16_v2.hip; the row (A)
+//     images RL / RH still arrive by LDS-DMA;
+//   * the column (weight) images CL / CH are filled THROUGH REGISTERS: every thread owns two 16-byte pieces of each 64 x 128 K-major
+//     image (the piece -> (k, 8 columns) map of dma_setup<KM>, so the fragment reads do not change), fetches their 8 fp32 with two
+//     `buffer_load_dwordx4` (inline asm: hipcc would wait vmcnt(0) for an ordinary load beside LDS-DMA, guide section 5 item 4b),
+//     converts with v_cvt_pk_bf16_f32 (round to nearest even = torch's cast, so results are bit-identical to "cast, then GEMM")
+//     and writes one `ds_write_b128`.  One register set of 16 VGPRs: image X is loaded during one phase and written at the start
+//     of the next -- CL(s+1) loaded in phase A(s), written in B(s), read in A(s+1); CH(s+1) loaded in B(s), written in A(s+1), read
+//     in B(s+1).  The loads share the in-order vmcnt queue with the DMA pieces: vmcnt(4) at the start of A (the 4 row pieces issued
+//     after the CH loads stay in flight), vmcnt(0) at the start of B (everything older was issued a full phase ago);
+//   * the tiles of an expert's FIRST row tile also store the converted pieces to a bf16 copy of the weights (`b_copy`), which the two
+//     backward GEMMs of the step read through the plain LDS-DMA kernels -- experts without rows write nothing and are read by nobody.
+#include "gemm_tiles.h"
+#include <algorithm>
+
+using namespace ggt;
+
+namespace {
+
+constexpr int BMc = 256, BNc = 256, BKc = 64;
+constexpr int CTc_LD = BNc + 4;
+constexpr int LDSc_BYTES = 128 * CTc_LD * 4;
+
+struct CvtArgs {
+  const void* R; int64_t ld_r;
+  const void* const* b_ptrs; const void* single_B; int64_t ld_c;          // fp32 [Kd, N]
+  void* const* copy_ptrs; void* single_copy;                              // bf16 [Kd, N] (leading dim NC) or null
+  const void* const* bias_ptrs; const void* single_bias;
+  const int32_t* offsets; int E; int single_M;
+  int NC, Kd;
+  void* C; void* C2; const void* aux; int64_t ldc;
+  int epilogue, act;
+};
+
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
+  return v;
+}
+
+__global__ void __launch_bounds__(512, 2) gg8c_kernel(CvtArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int e, row0, rows, tc0, mt;
+  const int nct = (p.NC + BNc - 1) / BNc;
+  {
+    const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BMc, nct, lane);
+    if ((int)blockIdx.x >= total) return;
+    const int v = xcd_remap(blockIdx.x, total);
+    TilePos tp;
+    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BMc, nct, v, lane, tp)) return;
+    e = tp.e; mt = tp.mt;
+    row0 = tp.o0 + tp.mt * BMc; rows = min(BMc, tp.o1 - row0);
+    tc0 = tp.nt * BNc;
+  }
+  e = __builtin_amdgcn_readfirstlane(e);
+  mt = __builtin_amdgcn_readfirstlane(mt);
+  row0 = __builtin_amdgcn_readfirstlane(row0);
+  rows = __builtin_amdgcn_readfirstlane(rows);
+  tc0 = __builtin_amdgcn_readfirstlane(tc0);
+  const int red_len = p.Kd;
+
+  const unsigned ldr_b = (unsigned)p.ld_r * 2u, ldw_b = (unsigned)p.ld_c * 4u;
+  __amdgpu_buffer_rsrc_t rs_r, rs_w;
+  unsigned vb_rl[2], vb_rh[2];
+  int ax_r[2], ax_dummy[2];
+  rs_r = make_rsrc((const char*)p.R + (int64_t)row0 * ldr_b, (unsigned)rows * ldr_b);
+  dma_setup<KC, 2>(vb_rl, ax_r, ldr_b, 0, 0, 7, 0, 0, wave, lane);
+  dma_setup<KC, 2>(vb_rh, ax_dummy, ldr_b, 0, 0, 7, 0, 128, wave, lane);
+  const char* wb = (const char*)(p.b_ptrs ? p.b_ptrs[e] : p.single_B);
+  rs_w = make_rsrc(wb, (unsigned)p.Kd * ldw_b);
+  bf16* copy = (bf16*)(p.copy_ptrs ? p.copy_ptrs[e] : p.single_copy);
+  const bool do_copy = copy != nullptr && mt == 0;
+
+  // this thread's two pieces of a K-major image: piece P = (wave * 2 + j) * 64 + lane -> (k, 8 columns from `ic`), as dma_setup<KM>
+  unsigned w_off[2][2];        // [image CL / CH][piece]: byte offset inside a K-tile of the fp32 source, or OOB
+  int c_k[2], c_col[2][2];     // k row of the piece; first column (tile-relative, image included) for the bf16 copy
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int P = (wave * 2 + j) * 64 + lane;
+    const int k = P >> 4, pc = P & 15;
+    const int f = (k & 3) | (((k >> 3) & 1) << 2);
+    const int seg = (pc >> 1) ^ f;
+    const int ic = seg * 16 + (pc & 1) * 8;
+    c_k[j] = k;
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+      const int col = tc0 + im * 128 + ic;
+      c_col[im][j] = col;
+      w_off[im][j] = (col < p.NC) ? ((unsigned)k * ldw_b + (unsigned)col * 4u) : OOB;       // N % 8 == 0: a piece is all in or all out
+    }
+  }
+
+  const int g = lane >> 4, i16 = lane & 15;
+  const int kc_lane = i16 * 128 + ((g ^ (i16 >> 1)) << 4);
+  const int q = i16 >> 2, pp = i16 & 3;
+  const int fk = q | ((g & 1) << 2);
+  const int r_blk0 = wm * 4, c_blk0 = wn * 2;
+  int km_c[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) km_c[b] = (8 * g + q) * 256 + (((c_blk0 + b) ^ fk) << 5) + pp * 8;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (red_len + BKc - 1) / BKc;
+
+#define SLOT(kind, tile) (smem + ((((tile) & 1) * 4 + (kind)) * TILE_B))
+#define ISSUE_RL(tile) dma_tile<KC, 2>(rs_r, SLOT(0, tile), vb_rl, ax_r, (tile) * BKc, red_len, ldr_b, wave)
+#define ISSUE_RH(tile) dma_tile<KC, 2>(rs_r, SLOT(3, tile), vb_rh, ax_r, (tile) * BKc, red_len, ldr_b, wave)
+#define PHASE_SYNC_IN()                                \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+  __builtin_amdgcn_s_barrier();                        \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  __builtin_amdgcn_s_setprio(1)
+#define EPI_SYNC()                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+  __builtin_amdgcn_s_barrier();                        \
+  asm volatile("" ::: "memory")
+#define PHASE_SYNC_OUT()                               \
+  __builtin_amdgcn_s_setprio(0);                       \
+  __builtin_amdgcn_sched_barrier(0);                   \
+  __builtin_amdgcn_s_barrier();                        \
+  __builtin_amdgcn_sched_barrier(0)
+  // the four fp32 quads of one image of K-tile `tile` (rows past Kd fall off the descriptor: zeros)
+#define LOAD_IMG(im, tile)                                                                           \
+  do {                                                                                               \
+    const unsigned kt_ = (unsigned)(tile) * (unsigned)BKc * ldw_b;                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
+      const unsigned o_ = w_off[im][j] == OOB ? OOB : w_off[im][j] + kt_;                            \
+      wr[2 * j] = bload4(rs_w, o_);                                                                  \
+      wr[2 * j + 1] = bload4(rs_w, o_ == OOB ? OOB : o_ + 16u);                                      \
+    }                                                                                                \
+  } while (0)
+  // wait until all but the N youngest vector-memory operations of this wave are done; the asm "modifies" the staging registers so
+  // that no conversion of them can be scheduled above the wait
+#define WAIT_W(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]) :: "memory")
+  // convert the staged quads and write them as the two pieces of image `kind` (1 = CL, 2 = CH) of K-tile `tile`
+#define STORE_IMG(kind, im, tile)                                                                    \
+  do {                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
+      const f32x4 a_ = wr[2 * j], b_ = wr[2 * j + 1];                                                \
+      bf16x8 o_;                                                                                     \
+      o_[0] = (bf16)a_[0]; o_[1] = (bf16)a_[1]; o_[2] = (bf16)a_[2]; o_[3] = (bf16)a_[3];            \
+      o_[4] = (bf16)b_[0]; o_[5] = (bf16)b_[1]; o_[6] = (bf16)b_[2]; o_[7] = (bf16)b_[3];            \
+      *(bf16x8*)(SLOT(kind, tile) + ((wave * 2 + j) * 64 + lane) * 16) = o_;                         \
+      if (do_copy) {                                                                                 \
+        const int kk_ = (tile) * BKc + c_k[j];                                                       \
+        if (kk_ < p.Kd && c_col[im][j] < p.NC) *(bf16x8*)(copy + (int64_t)kk_ * p.NC + c_col[im][j]) = o_;  \
+      }                                                                                              \
+    }                                                                                                \
+  } while (0)
+
+  const int rows_here = rows - wm * 64;
+  const int cols_here = min(BNc, p.NC - tc0) - wn * 32;
+  const bool actA = rows_here > 0 && cols_here > 0, actAh = rows_here > 128 && cols_here > 0;
+  const bool actB = rows_here > 0 && cols_here > 128, actBh = rows_here > 128 && cols_here > 128;
+
+  f32x4 wr[4];
+  // prologue: rows of K-tiles 0 and 1 by DMA; CL(0) through registers; CH(0) left in flight for phase A(0)
+  ISSUE_RL(0); ISSUE_RH(0);
+  LOAD_IMG(0, 0);
+  WAIT_W(0);
+  STORE_IMG(1, 0, 0);
+  LOAD_IMG(1, 0);
+  ISSUE_RL(1); ISSUE_RH(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  for (int s = 0; s < nk; ++s) {
+    const char* base = smem + (s & 1) * (4 * TILE_B);
+    const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
+    bf16x8 fc[2][2], fr[8][2];
+    // ---- phase A: CH(s) from the registers into LDS; fragments of CL, RL, RH(s); loads of CL(s+1)
+    WAIT_W(4);                                             // CH(s) quads are in (the 4 row pieces issued after them stay in flight)
+    STORE_IMG(2, 1, s);
+    if (actA) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_cl, km_c[cb], ks);
+    }
+    if (actA || actB) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_kc(i_rl, kc_lane, r_blk0 + rb, ks);
+    }
+    if (actAh || actBh) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = frag_kc(i_rh, kc_lane, r_blk0 + rb, ks);
+    }
+    LOAD_IMG(0, s + 1);
+    PHASE_SYNC_IN();
+    if (actA) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+    }
+    if (actAh) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 4; rb < 8; ++rb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+    }
+    PHASE_SYNC_OUT();
+    // ---- phase B: CL(s+1) from the registers into LDS; fragments of CH(s); loads of CH(s+1); row pieces of K-tile s+2
+    WAIT_W(0);                                             // CL(s+1) quads are in; so are the row pieces of K-tile s+1 (a phase old)
+    STORE_IMG(1, 0, s + 1);
+    if (actB) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
+    }
+    LOAD_IMG(1, s + 1);
+    ISSUE_RL(s + 2); ISSUE_RH(s + 2);
+    PHASE_SYNC_IN();
+    if (actB) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+            acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
+    }
+    if (actBh) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 4; rb < 8; ++rb)
+            acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
+    }
+    PHASE_SYNC_OUT();
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+
+  // the loads / zero-fill DMAs of the K-tiles past the end may still be in flight: drain before the staging tile reuses LDS
+  WAIT_W(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---------------- epilogue (as gemm_bf16_v2.hip, row-space) ----------------
+  float* stg = (float*)smem;
+  const int ec = (threadIdx.x & 31) * 8;
+  const int er = threadIdx.x >> 5;
+  const int ncol = tc0 + ec;
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool post_bias = p.epilogue == CSMOE_EPI_ROUND_BIAS32_ACT;
+  if (ncol < p.NC && (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias)) {
+    const void* bias = p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias;
+    if (bias && post_bias) {
+      const f32x4 b0 = *(const f32x4*)((const float*)bias + ncol), b1 = *(const f32x4*)((const float*)bias + ncol + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bv[j] = b0[j]; bv[4 + j] = b1[j]; }
+    } else if (bias) {
+      bf16x8 b8 = *(const bf16x8*)((const bf16*)bias + ncol);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = (float)b8[j];
+    }
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const int m = wm * 64 + rb * 16 + i16;
+        const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
+        *(f32x4*)(stg + m * CTc_LD + n) = pass == 0 ? acc[cb][rb] : acc[cb][4 + rb];
+      }
+    EPI_SYNC();
+    if (ncol < p.NC) {
+      const int rlim = min(128, rows - pass * 128);
+#pragma unroll 1
+      for (int r = er; r < rlim; r += 16) {
+        const f32x4 lo = *(const f32x4*)(stg + r * CTc_LD + ec), hi = *(const f32x4*)(stg + r * CTc_LD + ec + 4);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const int64_t o = (int64_t)(row0 + pass * 128 + r) * p.ldc + ncol;
+        bf16x8 o0;
+        if (p.epilogue == CSMOE_EPI_ACTGRAD) {
+          const bf16x8 h8 = *(const bf16x8*)((const bf16*)p.aux + o);
+          float h[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { h[j] = (float)h8[j]; v[j] = (float)(bf16)v[j]; }
+          act_bwd8(h, p.act);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o0[j] = (bf16)(v[j] * h[j]);
+          *(bf16x8*)((bf16*)p.C + o) = o0;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (post_bias) { v[j] = (float)(bf16)v[j] + bv[j]; o0[j] = (bf16)v[j]; }
+            else { o0[j] = (bf16)(v[j] + bv[j]); v[j] = (float)o0[j]; }
+          }
+          if (p.C) *(bf16x8*)((bf16*)p.C + o) = o0;
+          if ((p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias) && p.C2) {
+            act_fwd8(v, p.act);
+            bf16x8 o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o1[j] = (bf16)v[j];
+            *(bf16x8*)((bf16*)p.C2 + o) = o1;
+          }
+        }
+      }
+    }
+    EPI_SYNC();
+  }
+}
+
+}  // namespace
+
+int gg8c_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int64_t ldb, void* const* copy_ptrs,
+                  const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2, const void* aux,
+                  int64_t ldc, int epilogue, int act, const void* single_B, void* single_copy, const void* single_bias, hipStream_t st) {
+  CvtArgs p{};
+  p.R = A; p.ld_r = lda; p.b_ptrs = b_ptrs; p.single_B = single_B; p.ld_c = ldb; p.copy_ptrs = copy_ptrs; p.single_copy = single_copy;
+  p.bias_ptrs = bias_ptrs; p.single_bias = single_bias; p.offsets = offsets; p.E = E; p.single_M = M;
+  p.NC = N; p.Kd = Kd; p.C = C; p.C2 = C2; p.aux = aux; p.ldc = ldc; p.epilogue = epilogue; p.act = act;
+  const int nct = (N + BNc - 1) / BNc;
+  const int64_t grid = (int64_t)nct * ((M + BMc - 1) / BMc + E);
+  if (grid <= 0) return CSMOE_OK;
+  if (grid > 0x7fffffff) { csmoe_set_error("grouped_gemm_f32w: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
+  static bool done = false;
+  if (!done) {
+    hipError_t er = hipFuncSetAttribute((const void*)gg8c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDSc_BYTES);
+    if (er != hipSuccess) { csmoe_set_error("hipFuncSetAttribute: %s", hipGetErrorString(er)); return CSMOE_ERR_LAUNCH; }
+    done = true;
+  }
+  hipLaunchKernelGGL(gg8c_kernel, dim3((unsigned)grid), dim3(512), LDSc_BYTES, st, p);
+  CSMOE_CHECK_LAUNCH("grouped_gemm_f32w");
+  return CSMOE_OK;
+}

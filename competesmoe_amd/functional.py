@@ -286,6 +286,7 @@ def _remember(t: torch.Tensor, op, copy: torch.Tensor) -> None:
 
 
 _CAST_OVERLAP = os.environ.get("CSMOE_CAST_OVERLAP", "1") != "0"
+_F32W_ON = os.environ.get("CSMOE_F32W", "1") != "0"          # A/B: 0 = cast the fp32 masters to bf16 first (round 1's path)
 _SIDE_STREAMS = {}
 
 
@@ -297,11 +298,20 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return st
 
 
-def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residual=None, before_gemm2=None):
-    """`before_gemm2`: a stream the launch stream must wait for before the second grouped GEMM (operand cast running beside GEMM 1)."""
+def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residual=None, before_gemm2=None, masters=None):
+    """`before_gemm2`: a stream the launch stream must wait for before the second grouped GEMM (operand cast running beside GEMM 1).
+    `masters` = (keys fp32, k_copy bf16, values fp32, v_copy bf16): the forward GEMMs read the fp32 masters and convert inside
+    their tile fill (csmoe_grouped_gemm_f32w), writing the bf16 copies the backward GEMMs read through `tab`'s pointer tables."""
     T = x2.shape[0]
     bins = ops.bin_tokens(idx, tab.E)
     xs = ops.dispatch_tokens(x2, bins)
+    if masters is not None:
+        keys, k_copy, values, v_copy = masters
+        hpre, hact = ops.grouped_gemm_f32w(xs, keys, bins.offsets, copy=k_copy, bias_ptrs=tab.b1_ptrs, epilogue=tab.epi1, act=tab.act,
+                                           want_c2=True, want_c=tab.act != L.ACT_RELU)
+        y = ops.grouped_gemm_f32w(hact, values, bins.offsets, copy=v_copy)
+        out = ops.combine(y, bins, idx, w, combine_mode, T, obias=obias, residual=residual)
+        return out, (bins, xs, hpre, hact, y)
     ld1 = tab.D if tab.layout == L.B_NK else tab.F
     ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
     # ReLU: act'(pre) = (act(pre) > 0), so the pre-activation is neither written (1.44 GB at the headline shape) nor re-read by the
@@ -453,6 +463,17 @@ class MoEFFNPacked(torch.autograd.Function):
         dev = x2.device
         k_hit = v_hit = False
         k_op = v_op = None
+        n_rows = x2.shape[0] * idx.shape[-1]
+        masters = None
+        if (_F32W_ON and not _WEIGHT_CACHE_ON and op == torch.bfloat16 and keys.dtype == torch.float32 and values.dtype == torch.float32
+                and keys.is_contiguous() and values.is_contiguous() and ops.f32w_ok(n_rows, F, D) and ops.f32w_ok(n_rows, Dout, F)):
+            # fp32 masters converted inside the forward GEMMs' tile fill (the reference's Triton kernel does the same per tile,
+            # cvmm.py:126-140); the bf16 copies the backward needs are a side output of those launches.  Not with the operand
+            # cache: a copy written this way lacks the experts that received no rows.
+            k_op = torch.empty(keys.shape, dtype=op, device=dev)
+            v_op = torch.empty(values.shape, dtype=op, device=dev)
+            masters = (keys, k_op, values, v_op)
+            k_hit = v_hit = True
         if _WEIGHT_CACHE_ON and keys.dtype != op:
             k_op, k_hit = _cached_copy(keys, op)
         if _WEIGHT_CACHE_ON and values.dtype != op:
@@ -499,7 +520,7 @@ class MoEFFNPacked(torch.autograd.Function):
                           w1_ptrs=ops.ptr_table(k_op, E, D * F * es), w2_ptrs=ops.ptr_table(v_op, E, F * Dout * es),
                           b1_ptrs=b1, b2_ptrs=None, param_dtype=keys.dtype, epi1=epi1)
         out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, ob, residual=None if residual is None else residual.contiguous(),
-                                  before_gemm2=side)
+                                  before_gemm2=side, masters=masters)
         ctx.has_residual = residual is not None
         if stats is not None:               # the activated scores, for the caller's `relu_pass_rate` log (moe.py:406-414)
             stats["hact"] = saved[3]

@@ -417,6 +417,28 @@ def grouped_gemm(A: torch.Tensor, b_ptrs: torch.Tensor, b_layout: int, ldb: int,
     return (Cm, C2) if want_c2 else Cm
 
 
+def grouped_gemm_f32w(A: torch.Tensor, B32: torch.Tensor, offsets: torch.Tensor, copy: Optional[torch.Tensor] = None,
+                      bias_ptrs: Optional[torch.Tensor] = None, epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE,
+                      aux: Optional[torch.Tensor] = None, want_c2: bool = False, want_c: bool = True):
+    """csmoe_grouped_gemm_f32w: A [M, Kd] bf16, B32 [E, Kd, N] FP32 masters converted inside the tile fill; `copy` [E, Kd, N] bf16
+    receives the converted weights of every expert that has rows."""
+    M, Kd = A.shape
+    E, _, N = B32.shape
+    Cm = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c else None
+    C2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c2 else None
+    bp = ptr_table(B32, E, Kd * N * 4)
+    cp = ptr_table(copy, E, Kd * N * 2) if copy is not None else None
+    with _timed("grouped_gemm_nn", 2.0 * M * N * Kd):
+        L.check(lib.csmoe_grouped_gemm_f32w(A.data_ptr(), A.stride(0), bp.data_ptr(), N, _ptr(cp), _ptr(bias_ptrs), offsets.data_ptr(), E, M,
+                                            N, Kd, _ptr(Cm), _ptr(C2), _ptr(aux), N, epilogue, act, _stream()), "grouped_gemm_f32w")
+    return (Cm, C2) if want_c2 else Cm
+
+
+def f32w_ok(M: int, N: int, Kd: int) -> bool:
+    """Shapes for which the fp32-master kernel is the right one (its 256 x 256 tiles need a big launch, as use_v2_rowspace)."""
+    return N >= 256 and Kd >= 128 and M >= 2048 and N % 8 == 0 and Kd % 8 == 0 and Kd * N * 4 < (1 << 31)
+
+
 def dense_gemm(A: torch.Tensor, B: torch.Tensor, b_layout: int, bias: Optional[torch.Tensor] = None,
                epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE, aux: Optional[torch.Tensor] = None, want_c2: bool = False,
                force_generic: bool = False, want_c: bool = True):

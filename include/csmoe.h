@@ -253,6 +253,17 @@ int csmoe_softplus_mean(const void* y, void* aff, int R, int D, int dtype, int a
 int csmoe_softplus_mean_bwd(const void* y, const void* daff, const void* dy_add, void* dy, int R, int D, int dtype, int aff_dtype,
                             int precise, csmoe_stream_t stream);
 
+/* Row-space grouped GEMM with the weights read straight from FP32 MASTERS: A [M, Kd] bf16, B_e = b_ptrs[e] [Kd, N] FP32 (leading
+ * dimension ldb), converted to bf16 inside the tile fill (global -> registers -> cvt -> LDS) -- what the reference's Triton kernel
+ * does per tile (`a.to(tl.bfloat16)`, moe_pretrain_model/layers/cvmm.py:126-140, fp32 `keys` / `values` under bf16 autocast) instead of
+ * a separate cast pass over the weights.  Bit-identical to "cast to bf16, then csmoe_grouped_gemm(CSMOE_B_KN)".  b_copy_ptrs[e]
+ * (may be null) receives the bf16 copy [Kd, N] of every expert that has rows -- the operand of the step's two backward products;
+ * experts without rows are not written.  Same epilogues, outputs and bias conventions as csmoe_grouped_gemm with dtype bf16.
+ * N % 8 == 0, Kd % 8 == 0, 16-byte aligned rows (else CSMOE_ERR_UNSUPPORTED: cast and use csmoe_grouped_gemm). */
+int csmoe_grouped_gemm_f32w(const void* A, int64_t lda, const void* const* b_ptrs, int64_t ldb, void* const* b_copy_ptrs,
+                            const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                            const void* aux, int64_t ldc, int epilogue, int act, csmoe_stream_t stream);
+
 /* ---- MXFP8 expert GEMMs (BASELINE.json config 5: shared-expert variant on the fp8 matrix pipe) -------------------------
  * The reference has no fp8 path: these entries have no upstream counterpart; the contract is the bf16 path's
  * result within the quantisation error (tests: <= 3e-2 relative to the bf16 oracle, <= 2e-3 to the oracle's own MXFP8 emulation).

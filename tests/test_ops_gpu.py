@@ -634,3 +634,39 @@ def test_sum_partials_and_chunk_offsets(E, P, N):
                 want.append(min(hi, lo + st))
         want.append(int(off[E]))
         assert co.tolist() == want
+
+
+@pytest.mark.parametrize("E,M,N,Kd", [(4, 2100, 256, 128), (8, 5000, 512, 320), (3, 3000, 776, 1032), (64, 9000, 1024, 512)])
+def test_grouped_gemm_from_fp32_masters_is_bit_identical_to_cast_then_gemm(E, M, N, Kd):
+    """csmoe_grouped_gemm_f32w converts the fp32 weight tiles inside the tile fill (cvmm.py:126-140 does the same per tile): the
+    result, every epilogue, and the bf16 copy it writes for the backward must equal "weights.to(bf16), then csmoe_grouped_gemm"
+    BIT FOR BIT (the conversion is the same round-to-nearest-even, the K order of the accumulation is the same).  Experts without
+    rows keep their slice of the copy untouched."""
+    g = torch.Generator().manual_seed(E + N)
+    off = make_groups(E, M, seed=N)                     # expert 1 is empty
+    offd = off.to(DEV)
+    A = torch.randn(M, Kd, generator=g).bfloat16().to(DEV)
+    W32 = (torch.randn(E, Kd, N, generator=g) / math.sqrt(Kd)).to(DEV)
+    Wb = W32.bfloat16()
+    bias = (torch.randn(E, N, generator=g) * 0.5).bfloat16().to(DEV)
+    bias32 = (torch.randn(E, N, generator=g) * 0.5).to(DEV)
+    bp = ops.ptr_table(Wb, E, Kd * N * 2)
+    copy = torch.full((E, Kd, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    c = ops.grouped_gemm_f32w(A, W32, offd, copy=copy)
+    ref = ops.grouped_gemm(A, bp, L.B_KN, N, N, offd, E)
+    assert torch.equal(c, ref)
+    for e in range(E):
+        if int(off[e + 1]) > int(off[e]):
+            assert torch.equal(copy[e], Wb[e]), e
+        else:
+            assert bool((copy[e] == 7.0).all()), e
+    pre, act = ops.grouped_gemm_f32w(A, W32, offd, bias_ptrs=ops.ptr_table(bias, E, N * 2), epilogue=L.EPI_BIAS_ACT, act=L.ACT_GELU,
+                                     want_c2=True)
+    rpre, ract = ops.grouped_gemm(A, bp, L.B_KN, N, N, offd, E, bias_ptrs=ops.ptr_table(bias, E, N * 2), epilogue=L.EPI_BIAS_ACT,
+                                  act=L.ACT_GELU, want_c2=True)
+    assert torch.equal(pre, rpre) and torch.equal(act, ract)
+    none, only = ops.grouped_gemm_f32w(A, W32, offd, bias_ptrs=ops.ptr_table(bias32, E, N * 4), epilogue=L.EPI_ROUND_BIAS32_ACT,
+                                       act=L.ACT_RELU, want_c2=True, want_c=False)
+    _, ronly = ops.grouped_gemm(A, bp, L.B_KN, N, N, offd, E, bias_ptrs=ops.ptr_table(bias32, E, N * 4), epilogue=L.EPI_ROUND_BIAS32_ACT,
+                                act=L.ACT_RELU, want_c2=True, want_c=False)
+    assert none is None and torch.equal(only, ronly)
