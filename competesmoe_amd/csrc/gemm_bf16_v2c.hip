@@ -9,10 +9,15 @@
 //     image (the piece -> (k, 8 columns) map of dma_setup<KM>, so the fragment reads do not change), fetches their 8 fp32 with two
 //     `buffer_load_dwordx4` (inline asm: hipcc would wait vmcnt(0) for an ordinary load beside LDS-DMA, guide section 5 item 4b),
 //     converts with v_cvt_pk_bf16_f32 (round to nearest even = torch's cast, so results are bit-identical to "cast, then GEMM")
-//     and writes one `ds_write_b128`.  The quads of K-tile s+2 are fetched in phase A(s) and written in phase A(s+1) -- two phases
-//     of lead, as the DMA images have (with one phase of lead the loop measured 20 % slower: HBM misses were exposed) -- which takes
-//     two staging sets (32 VGPRs) and therefore the row-cut BAL schedule (16 live fragments instead of WIDE's 20).  The loads share
-//     the in-order vmcnt queue with the DMA pieces; the counted waits are derived at the loop;
+//     and writes one `ds_write_b128`.  One register set of 16 VGPRs: image X is loaded during one phase and written at the start
+//     of the next -- CL(s+1) loaded in phase A(s), written in B(s), read in A(s+1); CH(s+1) loaded in B(s), written in A(s+1), read
+//     in B(s+1).  The loads share the in-order vmcnt queue with the DMA pieces: vmcnt(4) at the start of A (the 4 row pieces issued
+//     after the CH loads stay in flight), vmcnt(0) at the start of B (everything older was issued a full phase ago).
+//     Measured at the headline shape (gpurun_out r2k / r2l, same box): 7.74 ms per launch against 6.36 ms for the LDS-DMA kernel on
+//     pre-cast bf16 weights, the step 41.0 ms against 41.8 ms with the two cast passes -- a net 2 %, because the conversion's issue work
+//     (8 loads, 16 cvt, 4 ds_write_b128 per wave and K-tile) sits in the read sections between the barriers, not under the MFMAs.  A
+//     row-cut (BAL) variant with the quads fetched TWO phases ahead (32 staging VGPRs) was bit-identical too and SLOWER (8.17 ms): load
+//     latency is not what costs; next step = interleave that issue work into the MFMA sections (sched_group_barrier);
 //   * the tiles of an expert's FIRST row tile also store the converted pieces to a bf16 copy of the weights (`b_copy`), which the two
 //     backward GEMMs of the step read through the plain LDS-DMA kernels -- experts without rows write nothing and are read by nobody.
 #include "gemm_tiles.h"
@@ -165,52 +170,17 @@ __global__ void __launch_bounds__(512, 2) gg8c_kernel(CvtArgs p) {
 
   const int rows_here = rows - wm * 64;
   const int cols_here = min(BNc, p.NC - tc0) - wn * 32;
-  const bool rlo = rows_here > 0, rhi = rows_here > 128, clo = cols_here > 0, chi = cols_here > 128;
+  const bool actA = rows_here > 0 && cols_here > 0, actAh = rows_here > 128 && cols_here > 0;
+  const bool actB = rows_here > 0 && cols_here > 128, actBh = rows_here > 128 && cols_here > 128;
 
-  // Row-cut two-phase loop (the BAL schedule of gemm_bf16_v2.hip: A = {CL, CH, RL} x R_lo, B = RH x R_hi; 16 fragments live instead of
-  // WIDE's 20, which pays for the second staging register set).  Both column images of K-tile s+2 are FETCHED in phase A(s) and
-  // WRITTEN in phase A(s+1): two phases of lead, like the LDS-DMA images (one phase measured 20 % slower: HBM misses were exposed).
-  // Issue order per K-tile and wave: A: [8 quads of s+2] [RH(s+1): 2 pieces]   B: [RL(s+2): 2 pieces]   (+4 copy stores in A's write
-  // step on an expert's first row tile: they are older than everything the counted waits leave in flight, so the counts hold).
-  f32x4 wr[4], ws[4];      // CL quads, CH quads
-#define LOAD_BOTH(tile)                                                                              \
-  do {                                                                                               \
-    const unsigned kt_ = (unsigned)(tile) * (unsigned)BKc * ldw_b;                                   \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
-      const unsigned o0_ = w_off[0][j] == OOB ? OOB : w_off[0][j] + kt_;                             \
-      const unsigned o1_ = w_off[1][j] == OOB ? OOB : w_off[1][j] + kt_;                             \
-      wr[2 * j] = bload4(rs_w, o0_);                                                                 \
-      wr[2 * j + 1] = bload4(rs_w, o0_ == OOB ? OOB : o0_ + 16u);                                    \
-      ws[2 * j] = bload4(rs_w, o1_);                                                                 \
-      ws[2 * j + 1] = bload4(rs_w, o1_ == OOB ? OOB : o1_ + 16u);                                    \
-    }                                                                                                \
-  } while (0)
-#define WAIT_BOTH(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]), "+v"(ws[0]), "+v"(ws[1]), "+v"(ws[2]), "+v"(ws[3]) :: "memory")
-#define WAIT_DMA(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-#define STORE_ONE(Q, kind, im, tile)                                                                 \
-  do {                                                                                               \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
-      const f32x4 a_ = Q[2 * j], b_ = Q[2 * j + 1];                                                  \
-      bf16x8 o_;                                                                                     \
-      o_[0] = (bf16)a_[0]; o_[1] = (bf16)a_[1]; o_[2] = (bf16)a_[2]; o_[3] = (bf16)a_[3];            \
-      o_[4] = (bf16)b_[0]; o_[5] = (bf16)b_[1]; o_[6] = (bf16)b_[2]; o_[7] = (bf16)b_[3];            \
-      *(bf16x8*)(SLOT(kind, tile) + ((wave * 2 + j) * 64 + lane) * 16) = o_;                         \
-      if (do_copy) {                                                                                 \
-        const int kk_ = (tile) * BKc + c_k[j];                                                       \
-        if (kk_ < p.Kd && c_col[im][j] < p.NC) *(bf16x8*)(copy + (int64_t)kk_ * p.NC + c_col[im][j]) = o_;  \
-      }                                                                                              \
-    }                                                                                                \
-  } while (0)
-
-  // prologue: column images of K-tile 0 through registers, those of K-tile 1 left in flight; rows RL(0), RH(0), RL(1) by DMA
-  LOAD_BOTH(0);
-  WAIT_BOTH(0);
-  STORE_ONE(wr, 1, 0, 0);
-  STORE_ONE(ws, 2, 1, 0);
-  ISSUE_RL(0);
-  LOAD_BOTH(1);
-  ISSUE_RH(0); ISSUE_RL(1);
-  WAIT_DMA(12);                                            // RL(0) landed (8 quads + RH(0) + RL(1) stay in flight)
+  f32x4 wr[4];
+  // prologue: rows of K-tiles 0 and 1 by DMA; CL(0) through registers; CH(0) left in flight for phase A(0)
+  ISSUE_RL(0); ISSUE_RH(0);
+  LOAD_IMG(0, 0);
+  WAIT_W(0);
+  STORE_IMG(1, 0, 0);
+  LOAD_IMG(1, 0);
+  ISSUE_RL(1); ISSUE_RH(1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();
@@ -218,86 +188,85 @@ __global__ void __launch_bounds__(512, 2) gg8c_kernel(CvtArgs p) {
   for (int s = 0; s < nk; ++s) {
     const char* base = smem + (s & 1) * (4 * TILE_B);
     const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-    bf16x8 fc[4][2], fr[4][2];
-    // ---- phase A: fragments of CL, CH, RL(s); column images of K-tile s+1 from the registers into LDS; fetch those of s+2
-    if (clo && (rlo || rhi)) {
+    bf16x8 fc[2][2], fr[8][2];
+    // ---- phase A: CH(s) from the registers into LDS; fragments of CL, RL, RH(s); loads of CL(s+1)
+    WAIT_W(4);                                             // CH(s) quads are in (the 4 row pieces issued after them stay in flight)
+    STORE_IMG(2, 1, s);
+    if (actA) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_cl, km_c[cb], ks);
     }
-    if (chi && (rlo || rhi)) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
-    }
-    if (rlo && clo) {
+    if (actA || actB) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_kc(i_rl, kc_lane, r_blk0 + rb, ks);
     }
-    WAIT_BOTH(4);                                          // quads of K-tile s+1 are in (RH(s), RL(s+1) stay in flight)
-    STORE_ONE(wr, 1, 0, s + 1);
-    STORE_ONE(ws, 2, 1, s + 1);
-    LOAD_BOTH(s + 2);
-    ISSUE_RH(s + 1);
-    WAIT_DMA(12);                                          // RH(s) landed
-    PHASE_SYNC_IN();
-    if (rlo && clo) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-    }
-    if (rlo && chi) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int cb = 2; cb < 4; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-    }
-    PHASE_SYNC_OUT();
-    // ---- phase B: fragments of RH(s); row pieces RL(s+2)
-    if (rhi && clo) {
+    if (actAh || actBh) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_kc(i_rh, kc_lane, r_blk0 + rb, ks);
+        for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = frag_kc(i_rh, kc_lane, r_blk0 + rb, ks);
     }
-    ISSUE_RL(s + 2);
-    WAIT_DMA(12);                                          // RL(s+1) landed
+    LOAD_IMG(0, s + 1);
     PHASE_SYNC_IN();
-    if (rhi && clo) {
+    if (actA) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb)
-            acc[cb][4 + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][4 + rb], 0, 0, 0);
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
     }
-    if (rhi && chi) {
+    if (actAh) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int cb = 2; cb < 4; ++cb)
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 4; rb < 8; ++rb)
+            acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+    }
+    PHASE_SYNC_OUT();
+    // ---- phase B: CL(s+1) from the registers into LDS; fragments of CH(s); loads of CH(s+1); row pieces of K-tile s+2
+    WAIT_W(0);                                             // CL(s+1) quads are in; so are the row pieces of K-tile s+1 (a phase old)
+    STORE_IMG(1, 0, s + 1);
+    if (actB) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
+    }
+    LOAD_IMG(1, s + 1);
+    ISSUE_RL(s + 2); ISSUE_RH(s + 2);
+    PHASE_SYNC_IN();
+    if (actB) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
           for (int rb = 0; rb < 4; ++rb)
-            acc[cb][4 + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][4 + rb], 0, 0, 0);
+            acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
+    }
+    if (actBh) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 4; rb < 8; ++rb)
+            acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
     }
     PHASE_SYNC_OUT();
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
 
   // the loads / zero-fill DMAs of the K-tiles past the end may still be in flight: drain before the staging tile reuses LDS
-  WAIT_BOTH(0);
+  WAIT_W(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
