@@ -33,9 +33,11 @@
 // In-kernel s_memtime stamps of this loop (diagnostic build of round 1; its listing was not kept -- the persistent twin's is
 // profiles/r01/wgrad_stamps.txt): per phase ~450 cycles of
 // read/issue/wait, ~380 of MFMA and ~170 of release latency per barrier -- an LDS-DMA issue costs its wave 100-185 cycles.
-#include "gemm_tiles.h"
+#include "gemm_epilogue.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 using namespace ggt;
 
@@ -43,13 +45,25 @@ namespace {
 
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int CT2_LD = BN2 + 4;              // fp32 epilogue staging row stride (floats); 128 rows per pass
-constexpr int LDS2_BYTES = 128 * CT2_LD * 4; // 133,120 B  (>= 2 * BUF_B = 131,072 B)
+constexpr int LDS2_BYTES = EPI_LDS_BYTES;   // 135,168 B: the epilogue's bf16 staging tile (>= the 8 operand images = 131,072 B)
 
 enum { SHALLOW = 0, DEEP = 1, WIDE = 2, BAL = 3 };
+
+// Diagnostic build (-DCSMOE_STAMPS, tools/tile_stamps.py): every workgroup records where it ran (XCC / SE / CU) and the 100 MHz
+// s_memrealtime at entry, at the start and the end of its K-loop and at exit, into a buffer of their own (CSMOE_STAMP_FILE gets
+// the raw records after the launch): the gaps between one workgroup's exit and the next one's entry on the same CU are the
+// re-dispatch cost of the non-persistent grid.
+#ifdef CSMOE_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define RT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#else
+#define RT_STAMP(var) do { } while (0)
+#endif
 
 template <int ROWK, int COLK, int MODE, int SCHED>
 __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  RT_STAMP(st_entry);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;       // row half, column quarter
@@ -129,6 +143,7 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #pragma unroll
   for (int b = 0; b < 2; ++b) km_c[b] = (8 * g + q) * 256 + (((c_blk0 + b) ^ fk) << 5) + pp * 8;
 
+  RT_STAMP(st_setup);
   f32x4 acc[4][8];   // [column block][row block]
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -424,34 +439,25 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 
   }
 
+  RT_STAMP(st_loop_end);
   // the zero-fill DMAs of the K-tiles past the end may still be writing LDS: drain before the staging tile reuses it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
   // ---------------- epilogue: two passes of 128 rows through an fp32 LDS tile ----------------
-  float* stg = (float*)smem;
-  const int ec = (threadIdx.x & 31) * 8;       // this thread's 8 columns inside the 256-wide tile
-  const int er = threadIdx.x >> 5;             // 0..15
-  const int ncol = tc0 + ec;
-  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool post_bias = p.epilogue == CSMOE_EPI_ROUND_BIAS32_ACT;     // fp32 bias added to the ROUNDED product (cvmm + bias)
-  if (MODE == 0 && ncol < p.NC && (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias)) {
-    const void* bias = p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias;
-    if (bias && post_bias) {
-      const f32x4 b0 = *(const f32x4*)((const float*)bias + ncol), b1 = *(const f32x4*)((const float*)bias + ncol + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { bv[j] = b0[j]; bv[4 + j] = b1[j]; }
-    } else if (bias) {
-      bf16x8 b8 = *(const bf16x8*)((const bf16*)bias + ncol);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = (float)b8[j];
-    }
-  }
+  // ---------------- epilogue ----------------
+  if constexpr (MODE == 0) {
+    const EpiArgs ea{p.C, p.C2, p.aux, p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias, p.ldc, p.epilogue, p.act, p.NC};
+    rowspace_epilogue(ea, acc, smem, row0, rows, tc0, wm, wn, lane);
+  } else {
+    // weight-gradient form (kept for the MODE = 1 instantiation; the launched weight-gradient kernel is gemm_bf16_v2p.hip's):
+    // two passes of 128 rows through an fp32 LDS tile
+    float* stg = (float*)smem;
+    const int ec = (threadIdx.x & 31) * 8, er = threadIdx.x >> 5;
+    const int ncol = tc0 + ec;
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    {
-      // acc[cb][rb]: rb < 4 -> row image RL, rb >= 4 -> RH; cb < 2 -> column image CL, cb >= 2 -> CH
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -460,71 +466,45 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
           const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
           *(f32x4*)(stg + m * CT2_LD + n) = pass == 0 ? acc[cb][rb] : acc[cb][4 + rb];
         }
-    }
-    EPI_SYNC();
-    if (ncol < p.NC) {
-      if (MODE == 0) {
-        const int rlim = min(128, rows - pass * 128);
+      EPI_SYNC();
+      if (ncol < p.NC) {
+      char* Ce = (char*)(p.out_ptrs ? p.out_ptrs[e] : p.single_C);
+      const int rlim = min(128, p.NR - tr0 - pass * 128);
 #pragma unroll 1
-        for (int r = er; r < rlim; r += 16) {
-          const f32x4 lo = *(const f32x4*)(stg + r * CT2_LD + ec), hi = *(const f32x4*)(stg + r * CT2_LD + ec + 4);
+      for (int r = er; r < rlim; r += 16) {
+        f32x4 lo = *(const f32x4*)(stg + r * CT2_LD + ec), hi = *(const f32x4*)(stg + r * CT2_LD + ec + 4);
+        const int64_t o = (int64_t)(tr0 + pass * 128 + r) * p.ldc + ncol;
+        if (p.out_f32) {
+          f32x4* dst = (f32x4*)(Ce + o * 4);
+          if (p.accumulate) { lo += dst[0]; hi += dst[1]; }
+          dst[0] = lo; dst[1] = hi;
+        } else {
+          bf16x8* dst = (bf16x8*)(Ce + o * 2);
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          const int64_t o = (int64_t)(row0 + pass * 128 + r) * p.ldc + ncol;
-          bf16x8 o0;
-          if (p.epilogue == CSMOE_EPI_ACTGRAD) {
-            const bf16x8 h8 = *(const bf16x8*)((const bf16*)p.aux + o);
-            float h[8];
+          if (p.accumulate) {
+            const bf16x8 old = *dst;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { h[j] = (float)h8[j]; v[j] = (float)(bf16)v[j]; }
-            act_bwd8(h, p.act);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o0[j] = (bf16)(v[j] * h[j]);
-            *(bf16x8*)((bf16*)p.C + o) = o0;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              if (post_bias) { v[j] = (float)(bf16)v[j] + bv[j]; o0[j] = (bf16)v[j]; }      // act sees the fp32 sum
-              else { o0[j] = (bf16)(v[j] + bv[j]); v[j] = (float)o0[j]; }
-            }
-            if (p.C) *(bf16x8*)((bf16*)p.C + o) = o0;          // null: the caller keeps the activated output only (ReLU)
-            if ((p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias) && p.C2) {
-              act_fwd8(v, p.act);
-              bf16x8 o1;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) o1[j] = (bf16)v[j];
-              *(bf16x8*)((bf16*)p.C2 + o) = o1;
-            }
+            for (int j = 0; j < 8; ++j) v[j] += (float)old[j];
           }
-        }
-      } else {
-        char* Ce = (char*)(p.out_ptrs ? p.out_ptrs[e] : p.single_C);
-        const int rlim = min(128, p.NR - tr0 - pass * 128);
-#pragma unroll 1
-        for (int r = er; r < rlim; r += 16) {
-          f32x4 lo = *(const f32x4*)(stg + r * CT2_LD + ec), hi = *(const f32x4*)(stg + r * CT2_LD + ec + 4);
-          const int64_t o = (int64_t)(tr0 + pass * 128 + r) * p.ldc + ncol;
-          if (p.out_f32) {
-            f32x4* dst = (f32x4*)(Ce + o * 4);
-            if (p.accumulate) { lo += dst[0]; hi += dst[1]; }
-            dst[0] = lo; dst[1] = hi;
-          } else {
-            bf16x8* dst = (bf16x8*)(Ce + o * 2);
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (p.accumulate) {
-              const bf16x8 old = *dst;
+          bf16x8 o8;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] += (float)old[j];
-            }
-            bf16x8 o8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o8[j] = (bf16)v[j];
-            *dst = o8;
-          }
+          for (int j = 0; j < 8; ++j) o8[j] = (bf16)v[j];
+          *dst = o8;
         }
       }
+      }
+      EPI_SYNC();
     }
-    EPI_SYNC();
   }
+#ifdef CSMOE_STAMPS
+  if (threadIdx.x == 0 && g_stamp_buf) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the tile's own stores have left the wave
+    unsigned long long* d = g_stamp_buf + (size_t)blockIdx.x * 16;
+    d[0] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    d[1] = st_entry; d[2] = st_setup; d[3] = st_loop_end; d[4] = __builtin_amdgcn_s_memrealtime();
+    d[5] = ((unsigned long long)(unsigned)rows << 32) | (unsigned)nk;
+  }
+#endif
 }
 
 // CSMOE_GEMM_SCHED=1|2|3 forces DEEP / WIDE / BAL for every row-space launch (A/B runs); unset = the measured best per
@@ -567,6 +547,25 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
   int rc;
   const int sp = sched_pref(b_layout);
   const bool wide = sp == WIDE;
+#ifdef CSMOE_STAMPS
+  struct StampDump {
+    unsigned long long* buf; int64_t n; hipStream_t st;
+    ~StampDump() {
+      const char* path = getenv("CSMOE_STAMP_FILE");
+      if (!buf || !path) return;
+      (void)hipStreamSynchronize(st);
+      std::vector<unsigned long long> h((size_t)n * 16);
+      (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+      if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+      (void)hipFree(buf);
+    }
+  } stamp_dump{nullptr, grid, st};
+  if (getenv("CSMOE_STAMP_FILE")) {
+    (void)hipMalloc(&stamp_dump.buf, (size_t)grid * 128);
+    (void)hipMemsetAsync(stamp_dump.buf, 0, (size_t)grid * 128, st);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_stamp_buf), &stamp_dump.buf, sizeof(void*), 0, hipMemcpyHostToDevice, st);
+  }
+#endif
 #define LAUNCH_SCHED(S)                                                                                              \
   do {                                                                                                                \
     if (b_layout == CSMOE_B_NK) {                                                                                     \

@@ -20,7 +20,7 @@
 //     latency is not what costs; next step = interleave that issue work into the MFMA sections (sched_group_barrier);
 //   * the tiles of an expert's FIRST row tile also store the converted pieces to a bf16 copy of the weights (`b_copy`), which the two
 //     backward GEMMs of the step read through the plain LDS-DMA kernels -- experts without rows write nothing and are read by nobody.
-#include "gemm_tiles.h"
+#include "gemm_epilogue.h"
 #include <algorithm>
 
 using namespace ggt;
@@ -28,8 +28,7 @@ using namespace ggt;
 namespace {
 
 constexpr int BMc = 256, BNc = 256, BKc = 64;
-constexpr int CTc_LD = BNc + 4;
-constexpr int LDSc_BYTES = 128 * CTc_LD * 4;
+constexpr int LDSc_BYTES = EPI_LDS_BYTES;     // the epilogue's staging tile (>= the 8 operand images)
 
 struct CvtArgs {
   const void* R; int64_t ld_r;
@@ -130,10 +129,6 @@ __global__ void __launch_bounds__(512, 2) gg8c_kernel(CvtArgs p) {
   __builtin_amdgcn_s_barrier();                        \
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_setprio(1)
-#define EPI_SYNC()                                     \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-  __builtin_amdgcn_s_barrier();                        \
-  asm volatile("" ::: "memory")
 #define PHASE_SYNC_OUT()                               \
   __builtin_amdgcn_s_setprio(0);                       \
   __builtin_amdgcn_sched_barrier(0);                   \
@@ -270,72 +265,9 @@ __global__ void __launch_bounds__(512, 2) gg8c_kernel(CvtArgs p) {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---------------- epilogue (as gemm_bf16_v2.hip, row-space) ----------------
-  float* stg = (float*)smem;
-  const int ec = (threadIdx.x & 31) * 8;
-  const int er = threadIdx.x >> 5;
-  const int ncol = tc0 + ec;
-  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool post_bias = p.epilogue == CSMOE_EPI_ROUND_BIAS32_ACT;
-  if (ncol < p.NC && (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias)) {
-    const void* bias = p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias;
-    if (bias && post_bias) {
-      const f32x4 b0 = *(const f32x4*)((const float*)bias + ncol), b1 = *(const f32x4*)((const float*)bias + ncol + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { bv[j] = b0[j]; bv[4 + j] = b1[j]; }
-    } else if (bias) {
-      bf16x8 b8 = *(const bf16x8*)((const bf16*)bias + ncol);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = (float)b8[j];
-    }
-  }
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const int m = wm * 64 + rb * 16 + i16;
-        const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
-        *(f32x4*)(stg + m * CTc_LD + n) = pass == 0 ? acc[cb][rb] : acc[cb][4 + rb];
-      }
-    EPI_SYNC();
-    if (ncol < p.NC) {
-      const int rlim = min(128, rows - pass * 128);
-#pragma unroll 1
-      for (int r = er; r < rlim; r += 16) {
-        const f32x4 lo = *(const f32x4*)(stg + r * CTc_LD + ec), hi = *(const f32x4*)(stg + r * CTc_LD + ec + 4);
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const int64_t o = (int64_t)(row0 + pass * 128 + r) * p.ldc + ncol;
-        bf16x8 o0;
-        if (p.epilogue == CSMOE_EPI_ACTGRAD) {
-          const bf16x8 h8 = *(const bf16x8*)((const bf16*)p.aux + o);
-          float h[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { h[j] = (float)h8[j]; v[j] = (float)(bf16)v[j]; }
-          act_bwd8(h, p.act);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o0[j] = (bf16)(v[j] * h[j]);
-          *(bf16x8*)((bf16*)p.C + o) = o0;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (post_bias) { v[j] = (float)(bf16)v[j] + bv[j]; o0[j] = (bf16)v[j]; }
-            else { o0[j] = (bf16)(v[j] + bv[j]); v[j] = (float)o0[j]; }
-          }
-          if (p.C) *(bf16x8*)((bf16*)p.C + o) = o0;
-          if ((p.epilogue == CSMOE_EPI_BIAS_ACT || post_bias) && p.C2) {
-            act_fwd8(v, p.act);
-            bf16x8 o1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o1[j] = (bf16)v[j];
-            *(bf16x8*)((bf16*)p.C2 + o) = o1;
-          }
-        }
-      }
-    }
-    EPI_SYNC();
-  }
+  // ---------------- epilogue (gemm_epilogue.h) ----------------
+  const EpiArgs ea{p.C, p.C2, p.aux, p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias, p.ldc, p.epilogue, p.act, p.NC};
+  rowspace_epilogue(ea, acc, smem, row0, rows, tc0, wm, wn, lane);
 }
 
 }  // namespace

@@ -1,0 +1,159 @@
+// Epilogue of the 256x256 row-space grouped-GEMM kernels (gemm_bf16_v2.hip, gemm_bf16_v2c.hip, gemm_fp8.hip): the 8 waves' fp32
+// accumulators (wave (wm, wn): acc[cb][rb] = rows (rb>>2)*128 + wm*64 + (rb&3)*16 + lane%16, columns (cb>>1)*128 + wn*32 +
+// (cb&1)*16 + 4*(lane/16) + 0..3) -> bf16 rows in global memory with the bias / activation / activation-gradient variants of
+// include/csmoe.h.
+//
+// Per-workgroup stamps of the previous form (tools/tile_stamps.py, -DCSMOE_STAMPS; headline shape, balanced routing) priced the
+// epilogue at 12.5 us of a 300 us tile with a plain store and 24-27 us of a 134 us tile with the GELU variants -- and the SAME with
+// the global stores compiled out: the time was the instruction stream (run-time `epilogue` / `act` tests per element, fp32 staging
+// in two passes of 128 rows, four barriers).  This form
+//   * rounds to bf16 in registers and stages the whole 256-row tile ONCE (ds_write_b64, 132 KiB incl. row padding, one barrier):
+//     every variant of the interface applies its activation to the ROUNDED product, so nothing is lost by rounding first;
+//   * is instantiated per (variant, activation) with the choice made once per tile, so each row loop is straight-line code;
+//   * walks 16 rows per thread fully unrolled (row = t/32 + 16 i, 8 columns per thread: 512-byte row segments per half wave);
+//   * fetches the saved pre-activations of the activation-gradient variant before the staging, 16 loads in flight per thread.
+#pragma once
+#include "gemm_tiles.h"
+
+namespace ggt {
+
+struct EpiArgs {
+  void* C; void* C2; const void* aux; const void* bias;   // bias: this expert's row (bf16, or fp32 for ROUND_BIAS32_ACT) or null
+  int64_t ldc; int epilogue, act, NC;
+};
+
+constexpr int EPI_LD = 264;                         // staged row stride in bf16 elements (528 B: 16-byte aligned, 4 banks per row)
+constexpr int EPI_LDS_BYTES = 256 * EPI_LD * 2;     // 135,168 B
+
+enum { EC_PLAIN = 0, EC_BIAS = 1, EC_BIAS_ACT = 2, EC_R32_ACT = 3, EC_ACTGRAD = 4 };
+constexpr int ACT_RT = -1;                          // activation chosen at run time (the rarer ones share one instantiation)
+
+template <int ACT>
+__device__ __forceinline__ void epi_act_fwd8(float (&v)[8], int act_rt) {
+  if constexpr (ACT == ACT_RT) act_fwd8(v, act_rt); else act_fwd8(v, ACT);
+}
+template <int ACT>
+__device__ __forceinline__ void epi_act_bwd8(float (&h)[8], int act_rt) {
+  if constexpr (ACT == ACT_RT) act_bwd8(h, act_rt); else act_bwd8(h, ACT);
+}
+
+template <int CLS, int ACT>
+__device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][8], char* smem, int row0, int rows, int tc0,
+                                        int wm, int wn, int lane) {
+  bf16* stg = (bf16*)smem;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int ec = (threadIdx.x & 31) * 8;       // this thread's 8 columns inside the 256-wide tile
+  const int er = threadIdx.x >> 5;             // 0..15
+  const int ncol = tc0 + ec;
+  const bool col_ok = ncol < p.NC;
+
+  bf16x8 hq[16];
+  if constexpr (CLS == EC_ACTGRAD) {
+    if (col_ok) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = er + 16 * i;
+        if (r < rows) hq[i] = *(const bf16x8*)((const bf16*)p.aux + (int64_t)(row0 + r) * p.ldc + ncol);
+      }
+    }
+  }
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (CLS == EC_R32_ACT) {           // fp32 bias added to the ROUNDED product (cvmm + bias)
+    if (p.bias && col_ok) {
+      const f32x4 b0 = *(const f32x4*)((const float*)p.bias + ncol), b1 = *(const f32x4*)((const float*)p.bias + ncol + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bv[j] = b0[j]; bv[4 + j] = b1[j]; }
+    }
+  }
+
+  // ---- stage: accumulators (+ bf16 bias, added before the rounding as F.linear does) -> bf16 -> LDS
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (CLS == EC_BIAS || CLS == EC_BIAS_ACT) {
+      if (p.bias && tc0 + n < p.NC) {
+        const bf16x4 b4 = *(const bf16x4*)((const bf16*)p.bias + tc0 + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = (float)b4[j];
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+      const int m = (rb >> 2) * 128 + wm * 64 + (rb & 3) * 16 + i16;
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (CLS == EC_BIAS || CLS == EC_BIAS_ACT) o[j] = (bf16)(acc[cb][rb][j] + b[j]);
+        else o[j] = (bf16)acc[cb][rb][j];
+      }
+      *(bf16x4*)(stg + m * EPI_LD + n) = o;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS traffic only: __syncthreads() would also wait for the loads above
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- rows
+  if (!col_ok) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = er + 16 * i;
+    if (r < rows) {
+      bf16x8 o0 = *(const bf16x8*)(stg + r * EPI_LD + ec);
+      const int64_t o = (int64_t)(row0 + r) * p.ldc + ncol;
+      if constexpr (CLS == EC_PLAIN || CLS == EC_BIAS) {
+        *(bf16x8*)((bf16*)p.C + o) = o0;
+      } else if constexpr (CLS == EC_ACTGRAD) {
+        float h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (float)hq[i][j];
+        epi_act_bwd8<ACT>(h, p.act);
+        bf16x8 o1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o1[j] = (bf16)((float)o0[j] * h[j]);
+        *(bf16x8*)((bf16*)p.C + o) = o1;
+      } else {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)o0[j];
+        if constexpr (CLS == EC_R32_ACT) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { v[j] += bv[j]; o0[j] = (bf16)v[j]; }     // the activation sees the fp32 sum
+        }
+        if (p.C) *(bf16x8*)((bf16*)p.C + o) = o0;            // null: the caller keeps the activated output only (ReLU)
+        if (p.C2) {
+          epi_act_fwd8<ACT>(v, p.act);
+          bf16x8 o1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o1[j] = (bf16)v[j];
+          *(bf16x8*)((bf16*)p.C2 + o) = o1;
+        }
+      }
+    }
+  }
+}
+
+template <int CLS>
+__device__ __forceinline__ void epi_by_act(const EpiArgs& p, const f32x4 (&acc)[4][8], char* smem, int row0, int rows, int tc0,
+                                           int wm, int wn, int lane) {
+  if (p.act == CSMOE_ACT_GELU) epi_run<CLS, CSMOE_ACT_GELU>(p, acc, smem, row0, rows, tc0, wm, wn, lane);
+  else if (p.act == CSMOE_ACT_RELU) epi_run<CLS, CSMOE_ACT_RELU>(p, acc, smem, row0, rows, tc0, wm, wn, lane);
+  else epi_run<CLS, ACT_RT>(p, acc, smem, row0, rows, tc0, wm, wn, lane);
+}
+
+// Called by all 512 threads after the K-loop's LDS traffic has drained (the staging tile overlays the operand images).
+__device__ __forceinline__ void rowspace_epilogue(const EpiArgs& p, const f32x4 (&acc)[4][8], char* smem, int row0, int rows,
+                                                  int tc0, int wm, int wn, int lane) {
+  switch (p.epilogue) {
+    case CSMOE_EPI_ACTGRAD: epi_by_act<EC_ACTGRAD>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_ROUND_BIAS32_ACT: epi_by_act<EC_R32_ACT>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_BIAS_ACT: epi_by_act<EC_BIAS_ACT>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_BIAS:
+      if (p.bias) { epi_run<EC_BIAS, 0>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break; }
+      [[fallthrough]];
+    default: epi_run<EC_PLAIN, 0>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+  }
+}
+
+}  // namespace ggt

@@ -14,7 +14,7 @@
 //   * the e8m0 scales travel by LDS-DMA too (4 bytes per row and K-tile: one 256-byte wave-instruction per wave and K-tile --
 //     waves 0-3 the 256 row scales, waves 4-7 the 256 column scales), are read as bytes in phase A and handed to the MFMA as
 //     per-lane scale operands (lane l supplies the scale of ITS 32-element block).
-#include "gemm_tiles.h"
+#include "gemm_epilogue.h"
 #include <algorithm>
 
 using namespace ggt;
@@ -22,9 +22,9 @@ using namespace ggt;
 namespace {
 
 constexpr int BM8 = 256, BN8 = 256;
-constexpr int CT8_LD = BN8 + 4;
 constexpr int SC_OFF = 8 * TILE_B;                       // scale slots behind the 8 image slots: 2 x (1 KiB rows + 1 KiB columns)
-constexpr int LDS8_BYTES = 128 * CT8_LD * 4 + 4096;      // staging tile (>= 128 KiB of images) + the scale slots behind it
+constexpr int LDS8_BYTES = SC_OFF + 4096;                // 8 image slots + the scale slots behind them
+static_assert(LDS8_BYTES >= EPI_LDS_BYTES, "the epilogue's staging tile overlays the operand images");
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
@@ -122,10 +122,6 @@ __global__ void __launch_bounds__(512, 2) gg8f_kernel(Fp8Args p) {
   __builtin_amdgcn_s_barrier();                        \
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_setprio(1)
-#define EPI_SYNC()                                     \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
-  __builtin_amdgcn_s_barrier();                        \
-  asm volatile("" ::: "memory")
 #define PHASE_SYNC_OUT()                               \
   __builtin_amdgcn_s_setprio(0);                       \
   __builtin_amdgcn_sched_barrier(0);                   \
@@ -225,64 +221,9 @@ __global__ void __launch_bounds__(512, 2) gg8f_kernel(Fp8Args p) {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---------------- epilogue: the bf16 kernel's (two passes of 128 rows through an fp32 LDS tile) ----------------
-  float* stg = (float*)smem;
-  const int ec = (threadIdx.x & 31) * 8;
-  const int er = threadIdx.x >> 5;
-  const int ncol = tc0 + ec;
-  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (ncol < p.NC && (p.epilogue == CSMOE_EPI_BIAS || p.epilogue == CSMOE_EPI_BIAS_ACT)) {
-    const bf16* bias = (const bf16*)(p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias);
-    if (bias) {
-      bf16x8 b8 = *(const bf16x8*)(bias + ncol);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = (float)b8[j];
-    }
-  }
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const int m = wm * 64 + rb * 16 + i16;
-        const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
-        *(f32x4*)(stg + m * CT8_LD + n) = pass == 0 ? acc[cb][rb] : acc[cb][4 + rb];
-      }
-    EPI_SYNC();
-    if (ncol < p.NC) {
-      const int rlim = min(128, rows - pass * 128);
-#pragma unroll 1
-      for (int r = er; r < rlim; r += 16) {
-        const f32x4 lo = *(const f32x4*)(stg + r * CT8_LD + ec), hi = *(const f32x4*)(stg + r * CT8_LD + ec + 4);
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const int64_t o = (int64_t)(row0 + pass * 128 + r) * p.ldc + ncol;
-        bf16x8 o0;
-        if (p.epilogue == CSMOE_EPI_ACTGRAD) {
-          const bf16x8 h8 = *(const bf16x8*)((const bf16*)p.aux + o);
-          float h[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { h[j] = (float)h8[j]; v[j] = (float)(bf16)v[j]; }
-          act_bwd8(h, p.act);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o0[j] = (bf16)(v[j] * h[j]);
-          *(bf16x8*)((bf16*)p.C + o) = o0;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { o0[j] = (bf16)(v[j] + bv[j]); v[j] = (float)o0[j]; }
-          if (p.C) *(bf16x8*)((bf16*)p.C + o) = o0;
-          if (p.epilogue == CSMOE_EPI_BIAS_ACT && p.C2) {
-            act_fwd8(v, p.act);
-            bf16x8 o1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o1[j] = (bf16)v[j];
-            *(bf16x8*)((bf16*)p.C2 + o) = o1;
-          }
-        }
-      }
-    }
-    EPI_SYNC();
-  }
+  // ---------------- epilogue: the bf16 kernels' (gemm_epilogue.h) ----------------
+  const EpiArgs ea{p.C, p.C2, p.aux, p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias, p.ldc, p.epilogue, p.act, p.NC};
+  rowspace_epilogue(ea, acc, smem, row0, rows, tc0, wm, wn, lane);
 }
 
 }  // namespace

@@ -137,26 +137,46 @@ __device__ __forceinline__ bf16x8 frag_km_raw(const char* tile, int addr_cb, int
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below half a bf16 ulp), one v_exp + one v_rcp: the OCML erff costs
 // ~50 instructions and made the bias+GELU epilogue ~30 % of a K=4096 tile (profiles/r01).  The fp32 path (gemm_generic.hip)
 // keeps the exact erff.
-__device__ __forceinline__ float erf_as(float x, float& e_out) {   // returns erf(x); e_out = exp(-x*x)
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
-  const float e = __expf(-ax * ax);
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float r = 1.f - p * t * e;
+// Both formulas (GELU and its derivative) over 8 values as 4 pairs, written on 2-vectors so that the multiplies / adds / FMAs become packed fp32
+// instructions (v_pk_mul_f32, v_pk_add_f32, v_pk_fma_f32: two elements per issue slot); v_rcp_f32 / v_exp_f32 stay per element.
+// Per tile of the bias+GELU epilogue this arithmetic was ~15 us of a 134 us tile (tools/tile_stamps.py): VALU-bound, no MFMA beside it.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_splat(float c) { return f32x2{c, c}; }
+// erf(z) for a pair; e_out = exp(-z*z)
+__device__ __forceinline__ f32x2 erf_as2(f32x2 z, f32x2& e_out) {
+  const f32x2 az = {fabsf(z[0]), fabsf(z[1])};
+  const f32x2 d = pk_fma(pk_splat(0.3275911f), az, pk_splat(1.f));
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const f32x2 a2 = (az * az) * pk_splat(-1.44269504088896340736f);           // -z^2 * log2(e)
+  const f32x2 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+  f32x2 p = pk_fma(pk_splat(1.061405429f), t, pk_splat(-1.453152027f));
+  p = pk_fma(p, t, pk_splat(1.421413741f));
+  p = pk_fma(p, t, pk_splat(-0.284496736f));
+  p = pk_fma(p, t, pk_splat(0.254829592f));
+  const f32x2 r = pk_fma(-(p * t), e, pk_splat(1.f));
   e_out = e;
-  return copysignf(r, x);
+  return f32x2{copysignf(r[0], z[0]), copysignf(r[1], z[1])};
 }
-__device__ __forceinline__ float gelu_fast(float x) {
-  float e;
-  return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752440f, e));
+__device__ __forceinline__ void gelu_fast8(float (&v)[8]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 x = {v[2 * k], v[2 * k + 1]};
+    f32x2 e;
+    const f32x2 erf = erf_as2(x * pk_splat(0.70710678118654752440f), e);
+    const f32x2 y = (x * pk_splat(0.5f)) * (erf + pk_splat(1.f));
+    v[2 * k] = y[0]; v[2 * k + 1] = y[1];
+  }
 }
-__device__ __forceinline__ float gelu_grad_fast(float x) {
-  float e;   // exp(-x^2/2)
-  const float cdf = 0.5f * (1.f + erf_as(x * 0.70710678118654752440f, e));
-  return fmaf(x * 0.39894228040143267794f, e, cdf);
+__device__ __forceinline__ void gelu_grad_fast8(float (&h)[8]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 x = {h[2 * k], h[2 * k + 1]};
+    f32x2 e;   // exp(-x^2/2)
+    const f32x2 erf = erf_as2(x * pk_splat(0.70710678118654752440f), e);
+    const f32x2 cdf = pk_fma(erf, pk_splat(0.5f), pk_splat(0.5f));
+    const f32x2 y = pk_fma(x * pk_splat(0.39894228040143267794f), e, cdf);
+    h[2 * k] = y[0]; h[2 * k + 1] = y[1];
+  }
 }
 
 // activation over 8 values, `switch` outside the element loop so each formula is emitted once
@@ -167,8 +187,7 @@ __device__ __forceinline__ void act_fwd8(float (&v)[8], int act) {
       for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j], CSMOE_ACT_RELU);
       break;
     case CSMOE_ACT_GELU:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = gelu_fast(v[j]);
+      gelu_fast8(v);
       break;
     case CSMOE_ACT_GELU_TANH:
 #pragma unroll
@@ -193,8 +212,7 @@ __device__ __forceinline__ void act_bwd8(float (&h)[8], int act) {
       for (int j = 0; j < 8; ++j) h[j] = act_bwd(h[j], CSMOE_ACT_RELU);
       break;
     case CSMOE_ACT_GELU:
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = gelu_grad_fast(h[j]);
+      gelu_grad_fast8(h);
       break;
     case CSMOE_ACT_GELU_TANH:
 #pragma unroll
