@@ -47,7 +47,7 @@ constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int CT2_LD = BN2 + 4;              // fp32 epilogue staging row stride (floats); 128 rows per pass
 constexpr int LDS2_BYTES = EPI_LDS_BYTES;   // 135,168 B: the epilogue's bf16 staging tile (>= the 8 operand images = 131,072 B)
 
-enum { SHALLOW = 0, DEEP = 1, WIDE = 2, BAL = 3 };
+enum { SHALLOW = 0, DEEP = 1, WIDE = 2, BAL = 3, PP = 4 };
 
 // Diagnostic build (-DCSMOE_STAMPS, tools/tile_stamps.py): every workgroup records where it ran (XCC / SE / CU) and the 100 MHz
 // s_memrealtime at entry, at the start and the end of its K-loop and at exit, into a buffer of their own (CSMOE_STAMP_FILE gets
@@ -107,19 +107,29 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   // Wave (wm, wn) owns rows {wm*64 + 0..63} of BOTH row images and columns {wn*32 + 0..31} of BOTH column images, i.e. four
   // 64x32 blocks of the 256x256 tile, so every image is consumed in exactly one phase by all eight waves.
   if (MODE == 0) {
+#ifdef CSMOE_SAME_TILE   // diagnostic: every tile reads the operands of tile (expert 0, rows 0.., columns 0..): the loop with all fetches L2 hits
+    rs_r = make_rsrc((const char*)p.R, (unsigned)rows * ldr_b);
+#else
     rs_r = make_rsrc((const char*)p.R + (int64_t)row0 * ldr_b, (unsigned)rows * ldr_b);
+#endif
     dma_setup<KC, 2>(vb_rl, ax_r, ldr_b, 0, 0, 7, 0, 0, wave, lane);
     dma_setup<KC, 2>(vb_rh, ax_dummy, ldr_b, 0, 0, 7, 0, 128, wave, lane);
+#ifdef CSMOE_SAME_TILE
+    const char* wb = (const char*)(p.c_ptrs_in ? p.c_ptrs_in[0] : p.single_B);
+    const int tc0_rd = 0;
+#else
     const char* wb = (const char*)(p.c_ptrs_in ? p.c_ptrs_in[e] : p.single_B);
+    const int tc0_rd = tc0;
+#endif
     if (COLK == KC) {
       int nrows = min(BN2, p.NC - tc0);
-      rs_c = make_rsrc(wb + (int64_t)tc0 * ldc_b, (unsigned)nrows * ldc_b);
+      rs_c = make_rsrc(wb + (int64_t)tc0_rd * ldc_b, (unsigned)nrows * ldc_b);
       dma_setup<KC, 2>(vb_cl, ax_c, ldc_b, 0, 0, 7, 0, 0, wave, lane);
       dma_setup<KC, 2>(vb_ch, ax_dummy, ldc_b, 0, 0, 7, 0, 128, wave, lane);
     } else {
       rs_c = make_rsrc(wb, (unsigned)p.Kd * ldc_b);
-      dma_setup<KM, 2>(vb_cl, ax_c, ldc_b, tc0, p.NC, 7, 0, 0, wave, lane);
-      dma_setup<KM, 2>(vb_ch, ax_dummy, ldc_b, tc0, p.NC, 7, 0, 128, wave, lane);
+      dma_setup<KM, 2>(vb_cl, ax_c, ldc_b, tc0_rd, p.NC, 7, 0, 0, wave, lane);
+      dma_setup<KM, 2>(vb_ch, ax_dummy, ldc_b, tc0_rd, p.NC, 7, 0, 128, wave, lane);
     }
   } else {
     rs_r = make_rsrc((const char*)p.R + (int64_t)row0 * ldr_b, (unsigned)red_len * ldr_b);
@@ -283,6 +293,89 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
       PHASE_SYNC_OUT();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
+  } else if constexpr (SCHED == PP) {
+    // BAL's phases (A: C_all x R_lo, B: C_all x R_hi) with ONE barrier per phase instead of two.  The two row halves do the two
+    // sections of a phase in OPPOSITE order between the same pair of barriers:
+    //     row half 0:  MFMA(q)  then  read the fragments of phase q+1 (+ its share of the DMA issue)
+    //     row half 1:  read the fragments of phase q (+ DMA issue)  then  MFMA(q)
+    // so one half's MFMAs still run beside its SIMD partner's LDS reads / DMA issue, but the switch between the sections is not a
+    // barrier any more: per-workgroup stamps put the release latency of a barrier at ~170 cycles, four of them per K-tile against
+    // 2,048 cycles of MFMA.  Row half 0 therefore reads every image one phase EARLIER than row half 1, which moves the landing
+    // deadlines up by a phase:
+    //     [CL,CH,RL](s+1) read by half 0 in B(s), by half 1 in A(s+1): landed (counted wait + barrier) by the end of A(s),
+    //                     its slot (that of K-tile s-1) is free from B(s-1) on  -> issued in B(s-1)
+    //     RH(s+1)         read by half 0 in A(s+1), by half 1 in B(s+1):  landed by the end of B(s), slot free from A(s) on
+    //                                                                     -> issued in A(s)
+    // Issue order ... [CL,CH,RL](s+1) | RH(s+1) | [CL,CH,RL](s+2) | ...: vmcnt(2) at the end of A(s) leaves RH(s+1) in flight,
+    // vmcnt(6) at the end of B(s) leaves [CL,CH,RL](s+2).  Half 0's reads are still in flight across the barrier (retired by the
+    // lgkmcnt(0) in front of its MFMAs); the slot they read is re-filled two phases later at the earliest.  The fragments are
+    // carried across the loop edge, so the reads are unconditional (a ragged tile reads rows the descriptor zero-filled).
+    const bool rlo = rows_here > 0, rhi = rows_here > 128, clo = cols_here > 0, chi = cols_here > 128;
+    bf16x8 fc[4][2], fr[4][2];
+#define PP_READ_C(tile)                                                                                               \
+    do {                                                                                                              \
+      const char* b_ = smem + ((tile) & 1) * (4 * TILE_B);                                                            \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
+          fc[cb][ks] = (COLK == KC) ? frag_kc(b_ + TILE_B, kc_lane, c_blk0 + cb, ks) : frag_km_raw(b_ + TILE_B, km_c[cb], ks); \
+          fc[2 + cb][ks] = (COLK == KC) ? frag_kc(b_ + 2 * TILE_B, kc_lane, c_blk0 + cb, ks) : frag_km_raw(b_ + 2 * TILE_B, km_c[cb], ks); \
+        }                                                                                                             \
+    } while (0)
+#define PP_READ_R(tile, kind)                                                                                         \
+    do {                                                                                                              \
+      const char* i_ = smem + ((tile) & 1) * (4 * TILE_B) + (kind) * TILE_B;                                          \
+      _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+          fr[rb][ks] = (ROWK == KC) ? frag_kc(i_, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_, km_r[rb], ks);          \
+    } while (0)
+#define PP_MFMA(RB0, on)                                                                                              \
+    do {                                                                                                              \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+      __builtin_amdgcn_s_setprio(1);                                                                                  \
+      if ((on) && clo) {                                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+          _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                            \
+            _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                          \
+              acc[cb][(RB0) + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][(RB0) + rb], 0, 0, 0); \
+      }                                                                                                               \
+      if ((on) && chi) {                                                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+          _Pragma("unroll") for (int cb = 2; cb < 4; ++cb)                                                            \
+            _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                          \
+              acc[cb][(RB0) + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][(RB0) + rb], 0, 0, 0); \
+      }                                                                                                               \
+      __builtin_amdgcn_s_setprio(0);                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+#define PP_END(N)                                                                                                     \
+    do {                                                                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+      WAIT_DMA(N);                                                                                                    \
+      __builtin_amdgcn_s_barrier();                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+    ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(0); ISSUE_RH(0); ISSUE_CL(1); ISSUE_CH(1); ISSUE_RL(1);
+    WAIT_DMA(8);                                           // CL, CH, RL(0) landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 0) { PP_READ_C(0); PP_READ_R(0, 0); }   // row half 0 enters the loop with the fragments of phase A(0)
+    WAIT_DMA(6);                                           // RH(0) landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < nk; ++s) {
+      // ---- A(s)
+      if (wm == 1) { PP_READ_C(s); PP_READ_R(s, 0); ISSUE_RH(s + 1); }
+      PP_MFMA(0, rlo);
+      if (wm == 0) { PP_READ_R(s, 3); ISSUE_RH(s + 1); }
+      PP_END(2);
+      // ---- B(s)
+      if (wm == 1) { PP_READ_R(s, 3); ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2); }
+      PP_MFMA(4, rhi);
+      if (wm == 0) { PP_READ_C(s + 1); PP_READ_R(s + 1, 0); ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2); }
+      PP_END(6);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // row half 0's reads of the (zero-filled) K-tile past the end
   } else if constexpr (SCHED == WIDE) {
     // TWO phases of 32 MFMA per K-tile (half the barriers of the 4-phase loop; all 8 row blocks stay in registers):
     //     phase A: read CL, RL, RH(s)   issue CL,CH(s+1)   vmcnt(8)   MFMA C_lo x R_all
@@ -499,7 +592,7 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #ifdef CSMOE_STAMPS
   if (threadIdx.x == 0 && g_stamp_buf) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the tile's own stores have left the wave
-    unsigned long long* d = g_stamp_buf + (size_t)blockIdx.x * 16;
+    unsigned long long* d = g_stamp_buf + (size_t)blockIdx.x * 8;
     d[0] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
     d[1] = st_entry; d[2] = st_setup; d[3] = st_loop_end; d[4] = __builtin_amdgcn_s_memrealtime();
     d[5] = ((unsigned long long)(unsigned)rows << 32) | (unsigned)nk;
@@ -507,8 +600,10 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #endif
 }
 
-// CSMOE_GEMM_SCHED=1|2|3 forces DEEP / WIDE / BAL for every row-space launch (A/B runs); unset = the measured best per
+// CSMOE_GEMM_SCHED=1|2|3|4 forces DEEP / WIDE / BAL / PP for every row-space launch (A/B runs); unset = the measured best per
 // layout: BAL for NT (both operands K-contiguous: +4 % over WIDE), WIDE for NN (K-major weights: BAL is 1-4 % slower there).
+// PP (one barrier per phase) is bit-identical and 2-4 % SLOWER than either on all four headline launches (gpurun_out r2r): the
+// barriers are not what the loop waits for -- see the stamp results in DESIGN.md section 3.
 int sched_pref(int b_layout) {
   static int v = -2;
   if (v == -2) {
@@ -554,15 +649,15 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
       const char* path = getenv("CSMOE_STAMP_FILE");
       if (!buf || !path) return;
       (void)hipStreamSynchronize(st);
-      std::vector<unsigned long long> h((size_t)n * 16);
+      std::vector<unsigned long long> h((size_t)n * 8);
       (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
       if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
       (void)hipFree(buf);
     }
   } stamp_dump{nullptr, grid, st};
   if (getenv("CSMOE_STAMP_FILE")) {
-    (void)hipMalloc(&stamp_dump.buf, (size_t)grid * 128);
-    (void)hipMemsetAsync(stamp_dump.buf, 0, (size_t)grid * 128, st);
+    (void)hipMalloc(&stamp_dump.buf, (size_t)grid * 64);
+    (void)hipMemsetAsync(stamp_dump.buf, 0, (size_t)grid * 64, st);
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_stamp_buf), &stamp_dump.buf, sizeof(void*), 0, hipMemcpyHostToDevice, st);
   }
 #endif
@@ -578,6 +673,7 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
     CSMOE_CHECK_LAUNCH("grouped_gemm(bf16 v2)");                                                                      \
     return CSMOE_OK;                                                                                                  \
   } while (0)
+  if (sp == PP) LAUNCH_SCHED(PP);
   if (sp == BAL) LAUNCH_SCHED(BAL);
   if (b_layout == CSMOE_B_NK) {
     if (wide) {

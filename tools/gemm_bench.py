@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--E", type=int, default=64)
     ap.add_argument("--D", type=int, default=4096)
     ap.add_argument("--F", type=int, default=11008)
+    ap.add_argument("--same-weights", action="store_true", help="every expert points at expert 0's matrices (weight panels stay cache-resident): what the loop does without the weight traffic")
     a = ap.parse_args()
     dev = "cuda"
     T, K, E, D, F = a.tokens, 2, a.E, a.D, a.F
@@ -48,6 +49,8 @@ def main():
     p1 = W1.data_ptr() + ar * (F * D * es)
     p2 = W2.data_ptr() + ar * (D * F * es)
     pb1 = b1.data_ptr() + ar * (F * es)
+    if a.same_weights:
+        p1, p2 = p1 * 0 + W1.data_ptr(), p2 * 0 + W2.data_ptr()
     gW1 = torch.empty(E, F, D, device=dev, dtype=bf)
     gW2 = torch.empty(E, D, F, device=dev, dtype=bf)
     pg1 = gW1.data_ptr() + ar * (F * D * es)

@@ -15,7 +15,7 @@ from competesmoe_amd import ops, _lib as L  # noqa: E402
 
 
 def analyse(path, name, ms):
-    a = np.fromfile(path, dtype=np.uint64).reshape(-1, 16)
+    a = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
     a = a[a[:, 1] != 0]
     hw = a[:, 0] & np.uint64(0xffffffff)
     xcc = (a[:, 0] >> np.uint64(32)) & np.uint64(0xf)
@@ -45,14 +45,13 @@ def analyse(path, name, ms):
     print(f"   full tiles ({int(full.sum())}, nk={int(np.median(nk))}): set-up {us(t[full, 1] - t[full, 0]):.2f} us, "
           f"K-loop (incl. first fetch) {us(t[full, 2] - t[full, 1]):.2f} us, epilogue {us(t[full, 3] - t[full, 2]):.2f} us, "
           f"total {us(t[full, 3] - t[full, 0]):.2f} us")
-    es = a[:, 8:15].astype(np.int64)
-    names = ["loop end -> drained", "pass 0 staged", "pass 0 stores issued (wave 0)", "pass 0 all waves", "pass 1 staged",
-             "pass 1 stores issued (wave 0)", "pass 1 all waves", "stores retired"]
-    pts = np.concatenate([t[:, 2:3], es, t[:, 3:4]], axis=1)[full]
-    print("   epilogue sections (us): " + ", ".join(f"{n} {us(pts[:, i + 1] - pts[:, i]):.2f}" for i, n in enumerate(names)))
     thin = ~full
     if thin.any():
-        print(f"   ragged tiles ({int(thin.sum())}, median rows {int(np.median(rows[thin]))}): total {us(t[thin, 3] - t[thin, 0]):.2f} us")
+        for lo, hi in ((1, 64), (65, 128), (129, 192), (193, 255)):
+            m = (rows >= lo) & (rows <= hi)
+            if m.any():
+                print(f"   ragged tiles of {lo}..{hi} rows ({int(m.sum())}): total {us(t[m, 3] - t[m, 0]):.2f} us, "
+                      f"K-loop {us(t[m, 2] - t[m, 1]):.2f} us")
     print(f"   gap exit -> next entry on the same CU: median {us(gaps):.2f} us, mean {0.01 * gaps.mean():.2f} us, "
           f"p90 {0.01 * np.percentile(gaps, 90):.2f} us, negative (overlap) {int((gaps < 0).sum())}")
 
