@@ -39,6 +39,10 @@ SIGNATURES = {
     "csmoe_router_select_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, C.c_float, _p, _p, _p, _p, _p, _p, _p]),
     "csmoe_bin_workspace_bytes": (_l, [_i, _i]),
     "csmoe_bin_tokens": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "csmoe_bin_tokens_hist": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "csmoe_gate_select_ok": (_i, [_i, _i, _i, _i, _i]),
+    "csmoe_gate_select_rows": (_i, []),
+    "csmoe_gate_select": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, C.c_float, _i, _p, _p, _p, _p, _p, _p]),
     "csmoe_dispatch_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "csmoe_dispatch_tokens": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "csmoe_dispatch_rows_bwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p]),

@@ -43,6 +43,10 @@ int k_router_select_bwd(const void*, int, int, int, int, int, int, float, const 
                         const float*, void*, hipStream_t);
 int64_t k_bin_workspace_bytes(int n, int E);
 int k_bin_tokens(const int32_t*, int, int, int32_t*, int32_t*, int32_t*, int32_t*, void*, hipStream_t);
+int k_bin_tokens_hist(const int32_t*, int, int, int, const int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, hipStream_t);
+bool k_gate_select_ok(int T, int D, int E, int K, int dtype, const void* x, const void* wg);
+int k_gate_select_rows();
+int k_gate_select(const void*, const void*, int, int, int, int, int, int, float, void*, float*, int32_t*, float*, int32_t*, hipStream_t);
 int k_dispatch_rows(const void*, const int32_t*, int, void*, int, int, int, hipStream_t);
 int k_dispatch_tokens(const void*, const int32_t*, int, void*, int, int, int, hipStream_t);
 int k_combine(const void*, const int32_t*, const int32_t*, const float*, const void*, const void*, void*, int, int, int, int, int,
@@ -181,6 +185,32 @@ int csmoe_bin_tokens(const int32_t* idx, int n, int E, int32_t* counts, int32_t*
   CSMOE_CHECK_ARG(n >= 0 && E > 0 && E <= 8192, "bin_tokens: bad n=%d E=%d", n, E);
   CSMOE_CHECK_ARG(counts && offsets && workspace && (n == 0 || (idx && perm && slot_of)), "bin_tokens: null pointer");
   return k_bin_tokens(idx, n, E, counts, offsets, perm, slot_of, workspace, (hipStream_t)stream);
+}
+
+int csmoe_bin_tokens_hist(const int32_t* idx, int n, int E, int chunk, const int32_t* block_hist, int32_t* block_base, int32_t* counts,
+                          int32_t* offsets, int32_t* perm, int32_t* slot_of, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(n >= 0 && E > 0 && E <= 8192 && chunk > 0, "bin_tokens_hist: bad n=%d E=%d chunk=%d", n, E, chunk);
+  CSMOE_CHECK_ARG(counts && offsets && block_hist && block_base && (n == 0 || (idx && perm && slot_of)), "bin_tokens_hist: null pointer");
+  return k_bin_tokens_hist(idx, n, E, chunk, block_hist, block_base, counts, offsets, perm, slot_of, (hipStream_t)stream);
+}
+
+int csmoe_gate_select_ok(int T, int D, int E, int K, int dtype) {
+  return T >= 0 && D > 0 && K > 0 && k_gate_select_ok(T, D, E, K, dtype, nullptr, nullptr) ? 1 : 0;
+}
+
+int csmoe_gate_select_rows(void) { return k_gate_select_rows(); }
+
+int csmoe_gate_select(const void* x, const void* w_gate, int T, int D, int E, int K, int sel_mode, int round_sum_bf16, float sel_param,
+                      int dtype, void* logits, float* softmax, int32_t* idx, float* w, int32_t* block_hist, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(T >= 0 && D > 0 && E > 0 && K > 0 && K <= E && K <= 64, "gate_select: bad shape T=%d D=%d E=%d K=%d", T, D, E, K);
+  CSMOE_CHECK_ARG(sel_mode >= 0 && sel_mode <= 4, "gate_select: bad mode %d", sel_mode);
+  CSMOE_CHECK_ARG(sel_mode != CSMOE_SEL_TOPK_SIGMOID || sel_param != 0.f, "gate_select: SEL_TOPK_SIGMOID needs a non-zero scale");
+  CSMOE_CHECK_ARG(k_gate_select_ok(T, D, E, K, dtype, x, w_gate),
+                  "gate_select: needs bf16, E <= 64, D a multiple of 8, 16-byte aligned operands (csmoe_gate_select_ok)");
+  if (T == 0) return CSMOE_OK;
+  CSMOE_CHECK_ARG(x && w_gate && logits && idx && w, "gate_select: null pointer");
+  return k_gate_select(x, w_gate, T, D, E, K, sel_mode, round_sum_bf16, sel_param, logits, softmax, idx, w, block_hist,
+                       (hipStream_t)stream);
 }
 
 int csmoe_dispatch_rows(const void* x, const int32_t* perm, int K, void* xs, int n, int D, int dtype, csmoe_stream_t stream) {

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#include "router_select.h"
 #include <algorithm>
 
 namespace {
@@ -13,25 +14,6 @@ namespace {
 //                   moe_pretrain_model/layers/moe/deepseekv2.py:140-142, deepseekv3.py:147-151)
 // One wave per token; lane l holds scores l, l+64, ... (VPL values per lane, E <= 64*VPL).
 // =====================================================================================================================
-__device__ __forceinline__ float round_dt(float v, int dtype) { return dtype == CSMOE_BF16 ? (float)(bf16)v : v; }
-__device__ __forceinline__ float load_score(const void* p, int64_t i, int dtype) {
-  return dtype == CSMOE_BF16 ? (float)((const bf16*)p)[i] : ((const float*)p)[i];
-}
-__device__ __forceinline__ void store_score(void* p, int64_t i, float v, int dtype) {
-  if (dtype == CSMOE_BF16) ((bf16*)p)[i] = (bf16)v; else ((float*)p)[i] = v;
-}
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-
-// wave arg-max with lowest-index tie break over (val, idx) pairs held one per lane
-__device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(v, o, 64);
-    int oi = __shfl_xor(i, o, 64);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-  }
-}
-
 template <int VPL>
 __global__ void __launch_bounds__(256) router_select_kernel(const void* scores, int dtype, int T, int E, int K, int mode,
                                                             int round_sum_bf16, float sel_param, float* softmax, int32_t* idx,
@@ -40,80 +22,14 @@ __global__ void __launch_bounds__(256) router_select_kernel(const void* scores, 
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
   const int64_t base = (int64_t)t * E;
-  float s[VPL], key[VPL];
-  float mx = -INFINITY;
+  float s[VPL];
 #pragma unroll
   for (int v = 0; v < VPL; ++v) {
     int e = lane + 64 * v;
     s[v] = e < E ? load_score(scores, base + e, dtype) : -INFINITY;
-    mx = fmaxf(mx, s[v]);
   }
-  mx = wave_max(mx);
-  // fp32 softmax of the scores (always produced when requested: losses need it)
-  float ex[VPL], sum = 0.f;
-#pragma unroll
-  for (int v = 0; v < VPL; ++v) {
-    int e = lane + 64 * v;
-    ex[v] = e < E ? expf(s[v] - mx) : 0.f;
-    sum += ex[v];
-  }
-  sum = wave_sum(sum);
-#pragma unroll
-  for (int v = 0; v < VPL; ++v) {
-    int e = lane + 64 * v;
-    float p = ex[v] / sum;
-    if (softmax && e < E) softmax[base + e] = p;
-    if (mode == CSMOE_SEL_SOFTMAX) key[v] = p;
-    else if (mode == CSMOE_SEL_SIGMOID) key[v] = round_dt(sigmoidf_(s[v]), dtype);
-    else key[v] = s[v];
-    if (e >= E) key[v] = -INFINITY;
-  }
-  // K rounds of wave arg-max, removing the winner each round
-  float vsum = 0.f;
-  float myv = 0.f;    // lane k keeps the k-th value
-  int myi = 0;
-  for (int k = 0; k < K; ++k) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      int e = lane + 64 * v;
-      if (key[v] > bv || (key[v] == bv && e < bi)) { bv = key[v]; bi = e; }
-    }
-    wave_argmax(bv, bi);
-#pragma unroll
-    for (int v = 0; v < VPL; ++v)
-      if (lane + 64 * v == bi) key[v] = -INFINITY;
-    if (lane == k) { myv = bv; myi = bi; }
-    vsum += bv;   // summed in k order, identical in every lane
-  }
-  if (mode == CSMOE_SEL_TOPK_SOFTMAX) {
-    // softmax over the K selected logits (fp32)
-    float top = __shfl(myv, 0, 64);
-    float ek = lane < K ? expf(myv - top) : 0.f;
-    float es = wave_sum(ek);
-    if (lane < K) { w[(int64_t)t * K + lane] = ek / es; idx[(int64_t)t * K + lane] = myi; }
-    return;
-  }
-  float denom, wk;
-  if (mode == CSMOE_SEL_TOPK_SIGMOID) {
-    // w_k = sigmoid(logit_k / scale) in the logits' dtype, renormalised by the fp32 K-sum rounded to x.dtype (quotient fp32)
-    const float sv = lane < K ? round_dt(sigmoidf_(round_dt(myv / sel_param, dtype)), dtype) : 0.f;
-    float ssum = 0.f;
-    for (int k = 0; k < K; ++k) ssum += __shfl(sv, k, 64);
-    denom = round_sum_bf16 ? (float)(bf16)ssum : ssum;
-    wk = sv / denom;
-  } else if (mode == CSMOE_SEL_SOFTMAX) {
-    denom = round_sum_bf16 ? (float)(bf16)vsum : vsum;
-    wk = myv / denom;
-  } else if (mode == CSMOE_SEL_RAW) {
-    denom = round_dt(vsum, dtype);
-    wk = round_dt(myv / denom, dtype);
-  } else {  // SIGMOID: fp32 sum of the K sigmoids (+1e-20), fp32 quotient
-    denom = vsum + 1e-20f;
-    wk = myv / denom;
-  }
-  if (lane < K) { w[(int64_t)t * K + lane] = wk; idx[(int64_t)t * K + lane] = myi; }
+  select_row<VPL>(s, lane, E, K, mode, round_sum_bf16, sel_param, dtype, softmax ? softmax + base : nullptr, idx + (int64_t)t * K,
+                  w + (int64_t)t * K);
 }
 
 template <int VPL>
@@ -207,32 +123,48 @@ __global__ void __launch_bounds__(256) bin_hist_kernel(const int32_t* idx, int n
   for (int i = threadIdx.x; i < E; i += 256) block_hist[(int64_t)blockIdx.x * E + i] = h[i];
 }
 
-__global__ void __launch_bounds__(1024) bin_scan_kernel(const int32_t* block_hist, int nb, int E, int32_t* counts,
+__global__ void __launch_bounds__(1024) bin_scan_kernel(const int32_t* block_hist, int nb, int E, int P, int32_t* counts,
                                                         int32_t* offsets, int32_t* block_base) {
-  extern __shared__ int32_t c[];   // counts, then exclusive offsets
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+  // P threads per expert, each over a contiguous range of blocks (thread i: expert i % E, part i / E: a block's E counts are
+  // read by consecutive threads).  One thread per expert walking all nb blocks was 100 us at nb = 512 (dependent L2 round trips).
+  extern __shared__ int32_t c[];   // [P*E] part sums -> exclusive part offsets, then [E] expert offsets
+  int32_t* eoff = c + P * E;
+  const int per = (nb + P - 1) / P;
+  for (int i = threadIdx.x; i < P * E; i += blockDim.x) {
+    const int e = i % E, p = i / E;
+    const int b0 = p * per, b1 = min(nb, b0 + per);
     int s = 0;
-    for (int b = 0; b < nb; ++b) s += block_hist[(int64_t)b * E + e];
-    c[e] = s;
-    counts[e] = s;
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) s += block_hist[(int64_t)b * E + e];
+    c[i] = s;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    int run = 0;
+    for (int p = 0; p < P; ++p) { const int v = c[p * E + e]; c[p * E + e] = run; run += v; }
+    counts[e] = run;
+    eoff[e] = run;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
-    for (int e = 0; e < E; ++e) { int v = c[e]; c[e] = run; offsets[e] = run; run += v; }
+    for (int e = 0; e < E; ++e) { const int v = eoff[e]; eoff[e] = run; offsets[e] = run; run += v; }
     offsets[E] = run;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    int run = c[e];
-    for (int b = 0; b < nb; ++b) {
+  for (int i = threadIdx.x; i < P * E; i += blockDim.x) {
+    const int e = i % E, p = i / E;
+    const int b0 = p * per, b1 = min(nb, b0 + per);
+    int run = eoff[e] + c[i];
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) {
       block_base[(int64_t)b * E + e] = run;
       run += block_hist[(int64_t)b * E + e];
     }
   }
 }
 
-__global__ void __launch_bounds__(256) bin_scatter_kernel(const int32_t* idx, int n, int E, int ebits,
+__global__ void __launch_bounds__(256) bin_scatter_kernel(const int32_t* idx, int n, int E, int ebits, int chunk,
                                                           const int32_t* block_base, int32_t* perm, int32_t* slot_of) {
   extern __shared__ int32_t sm[];
   int32_t* running = sm;          // [E]
@@ -241,10 +173,10 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(const int32_t* idx, in
   for (int i = threadIdx.x; i < E; i += 256) running[i] = block_base[(int64_t)blockIdx.x * E + i];
   for (int i = threadIdx.x; i < 4 * E; i += 256) wcnt[i] = 0;
   __syncthreads();
-  const int base = blockIdx.x * BIN_CHUNK;
-  for (int round = 0; round < BIN_CHUNK / 256; ++round) {
+  const int base = blockIdx.x * chunk;                 // `chunk` ids per workgroup: the block size the histogram was built with
+  for (int round = 0; round < (chunk + 255) / 256; ++round) {
     int j = base + round * 256 + threadIdx.x;
-    bool valid = j < n;
+    bool valid = j < n && round * 256 + (int)threadIdx.x < chunk;
     int e = valid ? idx[j] : -1;
     valid = valid && e >= 0 && e < E;
     // lanes of this wave holding the same expert
@@ -1297,6 +1229,13 @@ int k_router_select_bwd(const void* scores, int dtype, int T, int E, int K, int 
   return CSMOE_OK;
 }
 
+// threads per expert in bin_scan_kernel: as many as 1024 threads give, not more than there are blocks
+static int scan_parts(int nb, int E) {
+  int P = E <= 512 ? 1024 / E : 1;
+  if (P > nb) P = nb;
+  return P < 1 ? 1 : P;
+}
+
 int64_t k_bin_workspace_bytes(int n, int E) {
   int64_t nb = (n + BIN_CHUNK - 1) / BIN_CHUNK;
   return 2 * nb * (int64_t)E * 4 + 64;
@@ -1311,9 +1250,23 @@ int k_bin_tokens(const int32_t* idx, int n, int E, int32_t* counts, int32_t* off
   int ebits = 0;
   while ((1 << ebits) < E) ++ebits;
   hipLaunchKernelGGL(bin_hist_kernel, dim3(nb), dim3(256), E * 4, st, idx, n, E, block_hist);
-  hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), E * 4, st, block_hist, nb, E, counts, offsets, block_base);
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nb), dim3(256), 5 * E * 4, st, idx, n, E, ebits, block_base, perm, slot_of);
+  { const int P = scan_parts(nb, E); hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), (P + 1) * E * 4, st, block_hist, nb, E, P, counts, offsets, block_base); }
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nb), dim3(256), 5 * E * 4, st, idx, n, E, ebits, BIN_CHUNK, block_base, perm, slot_of);
   CSMOE_CHECK_LAUNCH("bin_tokens");
+  return CSMOE_OK;
+}
+
+// The same sort from a histogram somebody else built (the one-pass router, router_fused.hip): block b of the histogram counts ids
+// [b*chunk, (b+1)*chunk); scan + scatter only.
+int k_bin_tokens_hist(const int32_t* idx, int n, int E, int chunk, const int32_t* block_hist, int32_t* block_base, int32_t* counts,
+                      int32_t* offsets, int32_t* perm, int32_t* slot_of, hipStream_t st) {
+  int nb = (n + chunk - 1) / chunk;
+  if (nb == 0) nb = 1;
+  int ebits = 0;
+  while ((1 << ebits) < E) ++ebits;
+  { const int P = scan_parts(nb, E); hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), (P + 1) * E * 4, st, block_hist, nb, E, P, counts, offsets, block_base); }
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3(nb), dim3(256), 5 * E * 4, st, idx, n, E, ebits, chunk, block_base, perm, slot_of);
+  CSMOE_CHECK_LAUNCH("bin_tokens_hist");
   return CSMOE_OK;
 }
 

@@ -201,6 +201,48 @@ class RouterSelect(torch.autograd.Function):
         return ds, None, None, None, None
 
 
+class GateSelect(torch.autograd.Function):
+    """GateLogits + RouterSelect in ONE launch that reads x once (csmoe_gate_select): returns (logits, softmax fp32, idx int32,
+    w fp32) with the bits the two separate functions give.  `self.gate(x)` + `topk_expert` (moe_model/model/moe/smoe.py:42-44) /
+    `F.linear(x, w_gate)` + top-k (moe_pretrain_model/layers/moe/moe.py:121, smoe.py:30-40).  Backward: the selection's gradient plus
+    whatever the losses put on the logits, then the two gate products of GateLogits.backward."""
+
+    @staticmethod
+    def forward(ctx, x2: torch.Tensor, w_gate: torch.Tensor, K: int, mode: int, round_sum_bf16: bool, param: float = 1.0):
+        x2 = x2.contiguous()
+        wg = w_gate.contiguous()
+        if wg.dtype != x2.dtype:
+            wg = wg.to(x2.dtype)
+        logits, sm, idx, w = ops.gate_select(x2, wg, K, mode, round_sum_bf16, want_softmax=True, param=param)
+        ctx.save_for_backward(x2, wg, logits, sm, idx, w)
+        ctx.cfg = (K, mode, round_sum_bf16, param)
+        ctx.w_dtype = w_gate.dtype
+        ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
+        return logits, sm, idx, w
+
+    @staticmethod
+    def backward(ctx, dlogits, dsm, _didx, dw):
+        x2, wg, logits, sm, idx, w = ctx.saved_tensors
+        K, mode, rb, param = ctx.cfg
+        ds = None
+        if dsm is not None or dw is not None:
+            dsm = None if dsm is None else dsm.contiguous().float()
+            dw = None if dw is None else dw.contiguous().float()
+            ds = ops.router_select_bwd(logits, K, mode, rb, sm, idx, w, dw, dsm, param=param)
+        if dlogits is not None:
+            ds = dlogits.contiguous() if ds is None else ds + dlogits
+        if ds is None:
+            return None, None, None, None, None, None
+        dx = dwg = None
+        small = ops.gate_bwd_small_ok(x2.shape[1], wg.shape[0], x2.dtype)      # few experts: row passes, not MFMA tiles
+        if ctx.needs_input_grad[0]:
+            dx = ops.gate_bwd_dx(ds, wg) if small else ops.dense_gemm(ds, wg, L.B_KN)                     # [T,E] @ [E,D]
+        if ctx.needs_input_grad[1]:
+            dwg = ops.gate_bwd_dw(ds, x2, ctx.w_dtype) if small else _chunked_dense_wgrad(ds, x2, ctx.w_dtype)
+        return dx, dwg, None, None, None, None
+
+
 class RouterAux(torch.autograd.Function):
     """(balance loss fp32, z-loss in logits.dtype) of the LLaVA stack in two launches, one for the backward --
     `balanceloss` (moe_model/model/moe/moe.py:90-110: mean_n softmax x mean_n one_hot(top-1), mean over (b, e), x E^2) and

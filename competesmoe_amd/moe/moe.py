@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
-from ..functional import (ExpertTable, GateLogits, MoEFFNModules, MoEFFNModulesResidual, RouterSelect, DenseFFN, DiversityLoss,
+from ..functional import (ExpertTable, GateLogits, GateSelect, MoEFFNModules, MoEFFNModulesResidual, RouterSelect, DenseFFN, DiversityLoss,
                           RouterAux)
 from .. import ops
 
@@ -178,6 +178,13 @@ class MoeLayer(nn.Module):
     # ------------------------------------------------------------------ helpers shared by the sparse layers
     def _route(self, x) -> "Route":
         """Gate projection + softmax / top-K / renormalisation (smoe.py:42-44) as one record."""
+        B, N, D = x.shape
+        x2 = x.reshape(B * N, D)
+        K, E = self.num_selected, self.gate.weight.shape[0]
+        if getattr(self, "_pre_logits", None) is None and ops.gate_select_ok(x2, self.gate.weight, K):
+            # one launch that reads x once: logits, softmax, top-K and the binning histogram (csmoe_gate_select)
+            logits, sm, idx, w = GateSelect.apply(x2, self.gate.weight, K, L.SEL_SOFTMAX, x.dtype == torch.bfloat16)
+            return Route(logits.view(B, N, E), sm.view(B, N, E), idx.view(B, N, K), w.view(B, N, K))
         logits = self.gate_logits(x)
         w, idx, sm = self.topk_expert(gate_logits=logits)
         return Route(logits, sm, idx, w)

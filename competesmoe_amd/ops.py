@@ -99,6 +99,54 @@ def gate_logits(x2: torch.Tensor, w_gate: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# The block histogram of the last one-pass routing, handed to the bin_tokens call that sorts THOSE ids: (idx, its version counter,
+# histogram, ids per block).  Holding `idx` keeps its storage alive, so an equal data_ptr can only be a view of it, and the version
+# counter shows any in-place edit since; anything else falls back to the counting pass.
+_ROUTE_HIST = None
+
+
+def _route_hist_for(idx: torch.Tensor, E: int):
+    h = _ROUTE_HIST
+    if h is None:
+        return None
+    ref, ver, hist, chunk = h
+    if (idx.data_ptr() == ref.data_ptr() and idx.numel() == ref.numel() and idx._version == ver and ref._version == ver
+            and hist.shape[1] == E and idx.is_contiguous()):
+        return hist, chunk
+    return None
+
+
+def gate_select_ok(x2: torch.Tensor, w_gate: torch.Tensor, K: int) -> bool:
+    """Does the one-pass router (csmoe_gate_select) take this shape?  CSMOE_FUSED_ROUTER=0 turns it off (A/B runs)."""
+    if os.environ.get("CSMOE_FUSED_ROUTER", "1") == "0" or not x2.is_cuda:
+        return False
+    T, D = x2.shape
+    return bool(lib.csmoe_gate_select_ok(T, D, w_gate.shape[0], K, _dt(x2))) and x2.data_ptr() % 16 == 0 and w_gate.data_ptr() % 16 == 0
+
+
+def gate_select(x2: torch.Tensor, w_gate: torch.Tensor, K: int, mode: int, round_sum_bf16: bool, want_softmax: bool = True,
+                param: float = 1.0, want_hist: bool = True):
+    """(logits [T,E], softmax fp32 | None, idx [T,K] int32, w [T,K] fp32) in one launch that reads x2 once.  The launch also counts
+    the ids per block of rows; the bin_tokens call that sorts this `idx` (unmodified) picks the histogram up and skips its counting
+    pass."""
+    _need_cuda(x2, w_gate)
+    T, D = x2.shape
+    E = w_gate.shape[0]
+    dev = x2.device
+    logits = torch.empty(T, E, dtype=x2.dtype, device=dev)
+    sm = torch.empty(T, E, dtype=torch.float32, device=dev) if want_softmax else None
+    idx = torch.empty(T, K, dtype=torch.int32, device=dev)
+    w = torch.empty(T, K, dtype=torch.float32, device=dev)
+    rows = int(lib.csmoe_gate_select_rows())
+    hist = torch.empty((T + rows - 1) // rows, E, dtype=torch.int32, device=dev) if want_hist and T > 0 else None
+    with _timed("gate_select", T * D * x2.element_size()):
+        L.check(lib.csmoe_gate_select(x2.data_ptr(), w_gate.data_ptr(), T, D, E, K, mode, int(round_sum_bf16), float(param), _dt(x2),
+                                      logits.data_ptr(), _ptr(sm), idx.data_ptr(), w.data_ptr(), _ptr(hist), _stream()), "gate_select")
+    global _ROUTE_HIST
+    _ROUTE_HIST = (idx, idx._version, hist, rows * K) if hist is not None else None
+    return logits, sm, idx, w
+
+
 def router_select(scores: torch.Tensor, K: int, mode: int, round_sum_bf16: bool, want_softmax: bool = True, param: float = 1.0):
     _need_cuda(scores)
     T, E = scores.shape
@@ -242,7 +290,8 @@ def sum_partials(part: torch.Tensor, E: int, P: int, out_dtype) -> torch.Tensor:
     return out
 
 
-def bin_tokens(idx: torch.Tensor, E: int) -> Bins:
+def bin_tokens(idx: torch.Tensor, E: int, hist=None) -> Bins:
+    """`hist` = (block histogram [nb, E] int32, ids per block) from gate_select: scan + scatter only."""
     _need_cuda(idx)
     if idx.dtype != torch.int32:
         raise ValueError("csmoe: expert indices must be int32")
@@ -254,6 +303,16 @@ def bin_tokens(idx: torch.Tensor, E: int) -> Bins:
     offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(n, dtype=torch.int32, device=dev)
     slot_of = torch.empty(n, dtype=torch.int32, device=dev)
+    if hist is None:
+        hist = _route_hist_for(idx, E)
+    if hist is not None and n > 0:
+        bh, chunk = hist
+        if bh.shape != ((n + chunk - 1) // chunk, E) or bh.dtype != torch.int32:
+            raise ValueError("csmoe: block histogram does not match the ids it was built from")
+        base = torch.empty_like(bh)
+        L.check(lib.csmoe_bin_tokens_hist(idx.data_ptr(), n, E, chunk, bh.data_ptr(), base.data_ptr(), counts.data_ptr(),
+                                          offsets.data_ptr(), perm.data_ptr(), slot_of.data_ptr(), _stream()), "bin_tokens_hist")
+        return Bins(counts, offsets, perm, slot_of, n, E, K)
     ws = torch.empty(max(1, lib.csmoe_bin_workspace_bytes(n, E)), dtype=torch.uint8, device=dev)
     L.check(lib.csmoe_bin_tokens(idx.data_ptr(), n, E, counts.data_ptr(), offsets.data_ptr(), perm.data_ptr(),
                                  slot_of.data_ptr(), ws.data_ptr(), _stream()), "bin_tokens")

@@ -108,6 +108,25 @@ int64_t csmoe_bin_workspace_bytes(int n, int E);
 int csmoe_bin_tokens(const int32_t* idx, int n, int E, int32_t* counts, int32_t* offsets, int32_t* perm,
                      int32_t* slot_of, void* workspace, csmoe_stream_t stream);
 
+/* the same sort from a histogram built elsewhere (csmoe_gate_select): block_hist[nb][E] counts the ids of
+ * [b*chunk, (b+1)*chunk), nb = ceil(n / chunk); block_base[nb][E] is scratch.  Same outputs as csmoe_bin_tokens. */
+int csmoe_bin_tokens_hist(const int32_t* idx, int n, int E, int chunk, const int32_t* block_hist, int32_t* block_base,
+                          int32_t* counts, int32_t* offsets, int32_t* perm, int32_t* slot_of, csmoe_stream_t stream);
+
+/* ---- one-pass router -----------------------------------------------------------------------------------
+ * csmoe_gate_logits + csmoe_router_select (+ the counting pass of csmoe_bin_tokens) in ONE launch that reads x once:
+ *   logits[T,E] (dtype) = x[T,D] @ w_gate[E,D]^T;  softmax[T,E] fp32 (nullable), idx[T,K], w[T,K] as csmoe_router_select
+ *   gives them on those logits (identical bits: same selection routine);  block_hist (nullable): [ceil(T / rows)][E] counts of
+ *   the ids of each block of csmoe_gate_select_rows() token rows, i.e. chunk = rows*K for csmoe_bin_tokens_hist.
+ * Shapes it takes: csmoe_gate_select_ok(...) = 1 (bf16, E <= 64, D % 8 == 0); others use the two separate entries.
+ * replaces `self.gate(x)` + `topk_expert` (moe_model/model/moe/smoe.py:42-44, moe.py:113-132) and `F.linear(x, w_gate)` + top-k
+ * (moe_pretrain_model/layers/moe/moe.py:121, smoe.py:30-40, deepseekv2.py:140-142). */
+int csmoe_gate_select_ok(int T, int D, int E, int K, int dtype);
+int csmoe_gate_select_rows(void);
+int csmoe_gate_select(const void* x, const void* w_gate, int T, int D, int E, int K, int sel_mode, int round_sum_bf16,
+                      float sel_param, int dtype, void* logits, float* softmax, int32_t* idx, float* w, int32_t* block_hist,
+                      csmoe_stream_t stream);
+
 /* ---- dispatch / combine ------------------------------------------------------------------------------
  * dispatch: xs[m,:] = x[perm[m] / K, :]                      (gather of x rows, moe.py:201 `x[batch_idx, token_idx]`;
  *                                                             cvmm.py:114-119 remap_offs_am) */

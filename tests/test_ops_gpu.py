@@ -670,3 +670,71 @@ def test_grouped_gemm_from_fp32_masters_is_bit_identical_to_cast_then_gemm(E, M,
     _, ronly = ops.grouped_gemm(A, bp, L.B_KN, N, N, offd, E, bias_ptrs=ops.ptr_table(bias32, E, N * 4), epilogue=L.EPI_ROUND_BIAS32_ACT,
                                 act=L.ACT_RELU, want_c2=True, want_c=False)
     assert none is None and torch.equal(only, ronly)
+
+
+# ------------------------------------------------------------------------------------------------ one-pass router
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,E,K", [(1, 64, 4, 2), (63, 256, 8, 2), (65, 1152, 4, 2), (300, 264, 40, 4), (1000, 4096, 64, 2),
+                                     (257, 520, 16, 1), (128, 1024, 48, 8)])
+@pytest.mark.parametrize("mode", [L.SEL_SOFTMAX, L.SEL_SIGMOID, L.SEL_TOPK_SOFTMAX])
+def test_gate_select_equals_gate_then_select(T, D, E, K, mode):
+    """csmoe_gate_select = csmoe_gate_logits + csmoe_router_select + the counting pass of csmoe_bin_tokens.  The logits come from a
+    different kernel (another MFMA tiling of the same fp32 sums): equal to 1 bf16 ulp; on ITS OWN logits the selection must give the
+    bits router_select gives, and the bins built from its histogram must be the bins bin_tokens builds."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(T * 7 + E)
+    x = torch.randn(T, D, device=dev, generator=g).to(torch.bfloat16)
+    wg = (torch.randn(E, D, device=dev, generator=g) * D ** -0.5).to(torch.bfloat16)
+    assert ops.gate_select_ok(x, wg, K)
+    logits, sm, idx, w = ops.gate_select(x, wg, K, mode, True)
+    ref_logits = ops.gate_logits(x, wg)
+    d = (logits.float() - ref_logits.float()).abs()
+    assert (d <= 2.0 ** -7 * ref_logits.float().abs().clamp_min(2.0 ** -6)).all(), d.max()
+    exact = (x.double() @ wg.double().t())
+    assert (logits.double() - exact).abs().max() <= 2.0 ** -7 * exact.abs().max().clamp_min(1.0)
+    sm2, idx2, w2 = ops.router_select(logits, K, mode, True)
+    assert torch.equal(idx, idx2) and torch.equal(w, w2) and torch.equal(sm, sm2)
+    b_hist = ops.bin_tokens(idx, E)                 # picks the histogram of this routing up
+    assert ops._route_hist_for(idx, E) is not None
+    idx_copy = idx.clone()
+    b_plain = ops.bin_tokens(idx_copy, E)
+    assert ops._route_hist_for(idx_copy, E) is None
+    for a, b in ((b_hist.counts, b_plain.counts), (b_hist.offsets, b_plain.offsets), (b_hist.perm, b_plain.perm),
+                 (b_hist.slot_of, b_plain.slot_of)):
+        assert torch.equal(a, b)
+    idx[0, 0] = (idx[0, 0] + 1) % E                 # an in-place edit retires the histogram
+    assert ops._route_hist_for(idx, E) is None
+
+
+@pytest.mark.gpu
+def test_smoe_layer_fused_router_equals_two_launch_router(monkeypatch):
+    """The LLaVA `smoe` layer with the one-pass router against the same layer with CSMOE_FUSED_ROUTER=0: same routing, outputs and
+    gradients to the tolerance of the logits' different MFMA tiling."""
+    from competesmoe_amd.moe.smoe import SMoeLayer
+    import torch.nn as nn
+    dev = "cuda"
+    torch.manual_seed(3)
+    D, F, E, K = 256, 512, 8, 2
+    expert = nn.Sequential(nn.Linear(D, F), nn.GELU(), nn.Linear(F, D))
+    import types
+    args = types.SimpleNamespace(balance_loss_coef=0.01, router_z_loss_coef=0.001)
+    layer = SMoeLayer(D, D, E, K, expert, args).to(dev).to(torch.bfloat16)
+    x = (torch.randn(2, 96, D, device=dev) * 0.5).to(torch.bfloat16)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CSMOE_FUSED_ROUTER", flag)
+        xi = x.clone().requires_grad_(True)
+        layer.zero_grad(set_to_none=True)
+        out, aux, _, _ = layer(xi)
+        (out.float().pow(2).mean() + aux.float()).backward()
+        outs.append((out.detach().float(), aux.detach().float(), xi.grad.float(), layer.gate.weight.grad.float(),
+                     layer.log_metrics["selected_experts"].clone()))
+    a, b = outs
+    same_rows = (a[4] == b[4]).all(-1).float().mean().item()
+    assert same_rows >= 0.98, same_rows                              # a logit 1 ulp apart can flip a near-tie
+    assert (a[0] - b[0]).abs().max() <= 0.05 * b[0].abs().max() or same_rows < 1.0
+    if same_rows == 1.0:
+        assert torch.allclose(a[0], b[0], rtol=2e-2, atol=2e-3)
+        assert torch.allclose(a[1], b[1], rtol=1e-3, atol=1e-5)
+        assert torch.allclose(a[2], b[2], rtol=5e-2, atol=5e-3 * b[2].abs().max().item())
+        assert torch.allclose(a[3], b[3], rtol=5e-2, atol=5e-3 * b[3].abs().max().item())
