@@ -31,8 +31,7 @@ class _SharedBase(MoE):
         pass
 
     def forward(self, x, return_id_experts=False, return_full=True, *args, **kwargs):
-        gate_logits = self.compute_gate(x)
-        weights, selected_experts, gate_softmax = self.select(gate_logits, self.SEL, x.dtype)
+        gate_logits, weights, selected_experts, gate_softmax = self.gate_and_select(x, self.SEL, x.dtype)
         out = self.ffn(x, selected_experts, weights)
         out = out + self.shared_ffn(x, self.keys_shared, self.values_shared, self.bias_shared)
         bal = self.entropy_balance(gate_logits) * (self.args.balance_loss_coef / self.div)

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from .. import ops
-from ..functional import DenseFFN, DenseFFNFP8, GateLogits, MoEFFNPacked, MoEFFNPackedFP8, RouterSelect
+from ..functional import DenseFFN, DenseFFNFP8, GateLogits, GateSelect, MoEFFNPacked, MoEFFNPackedFP8, RouterSelect
 from .framework_layers import LoggingLayer, OncePerIterLayer, RegularizedLayer
 
 
@@ -142,6 +142,22 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         sm, idx, w = RouterSelect.apply(scores.reshape(-1, shp[-1]), self.num_selected, mode, x_dtype == torch.bfloat16)
         K = self.num_selected
         return w.view(*shp[:-1], K), idx.view(*shp[:-1], K), sm.view(shp)
+
+    def gate_and_select(self, x, mode, x_dtype):
+        """compute_gate + select -> (gate_logits, weights, selected_experts, gate_softmax); one launch that reads x once
+        (csmoe_gate_select, same bits) when the gate is the plain F.linear and the block has not computed the logits already."""
+        shp = x.shape
+        op = op_dtype(x)
+        K, E = self.num_selected, self.w_gate.shape[0]
+        if self._pre_logits is None and self._plain_gate() and op == torch.bfloat16:
+            x2 = x.reshape(-1, shp[-1]).to(op)
+            if ops.gate_select_ok(x2, self.w_gate, K):
+                sd = self._stream_dtype if self._stream_dtype is not None else x_dtype
+                lg, sm, idx, w = GateSelect.apply(x2, self.w_gate, K, mode, sd == torch.bfloat16)
+                return lg.view(*shp[:-1], E), w.view(*shp[:-1], K), idx.view(*shp[:-1], K), sm.view(*shp[:-1], E)
+        gate_logits = self.compute_gate(x)
+        w, idx, sm = self.select(gate_logits, mode, x_dtype)
+        return gate_logits, w, idx, sm
 
     def topk_expert(self, gate_logits, x_dtype=torch.float32):
         """softmax(fp32) -> top-k -> renormalised weights (smoe.py:123-143 + :236)."""

@@ -676,12 +676,13 @@ def test_grouped_gemm_from_fp32_masters_is_bit_identical_to_cast_then_gemm(E, M,
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,D,E,K", [(1, 64, 4, 2), (63, 256, 8, 2), (65, 1152, 4, 2), (300, 264, 40, 4), (1000, 4096, 64, 2),
                                      (257, 520, 16, 1), (128, 1024, 48, 8)])
-@pytest.mark.parametrize("mode", [L.SEL_SOFTMAX, L.SEL_SIGMOID, L.SEL_TOPK_SOFTMAX])
-def test_gate_select_equals_gate_then_select(T, D, E, K, mode):
+@pytest.mark.parametrize("mode_name", ["SEL_SOFTMAX", "SEL_SIGMOID", "SEL_TOPK_SOFTMAX", "SEL_RAW"])
+def test_gate_select_equals_gate_then_select(T, D, E, K, mode_name):
     """csmoe_gate_select = csmoe_gate_logits + csmoe_router_select + the counting pass of csmoe_bin_tokens.  The logits come from a
     different kernel (another MFMA tiling of the same fp32 sums): equal to 1 bf16 ulp; on ITS OWN logits the selection must give the
     bits router_select gives, and the bins built from its histogram must be the bins bin_tokens builds."""
     dev = "cuda"
+    mode = getattr(L, mode_name)
     g = torch.Generator(device=dev).manual_seed(T * 7 + E)
     x = torch.randn(T, D, device=dev, generator=g).to(torch.bfloat16)
     wg = (torch.randn(E, D, device=dev, generator=g) * D ** -0.5).to(torch.bfloat16)
