@@ -369,6 +369,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"ep{world} (experts sharded, RCCL all-to-all)",
                        **({"ep_chunks": layer.chunks, "ep_chunks_trial_ms": ep_tune} if (world > 1 or a.force_ep) else {})},
             "roofline": roof, "kernels": detail,
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -43,6 +43,7 @@ int k_router_select_bwd(const void*, int, int, int, int, int, int, float, const 
                         const float*, void*, hipStream_t);
 int64_t k_bin_workspace_bytes(int n, int E);
 int k_bin_tokens(const int32_t*, int, int, int32_t*, int32_t*, int32_t*, int32_t*, void*, hipStream_t);
+int k_affinity_finish(const float*, int, int, int, void*, int64_t, int, hipStream_t);
 int k_bin_tokens_hist(const int32_t*, int, int, int, const int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, hipStream_t);
 bool k_gate_select_ok(int T, int D, int E, int K, int dtype, const void* x, const void* wg);
 int k_gate_select_rows();
@@ -194,6 +195,13 @@ int csmoe_bin_tokens_hist(const int32_t* idx, int n, int E, int chunk, const int
   return k_bin_tokens_hist(idx, n, E, chunk, block_hist, block_base, counts, offsets, perm, slot_of, (hipStream_t)stream);
 }
 
+int csmoe_affinity_finish(const float* partial, int M, int ntiles, int D, void* aff, int64_t aff_stride, int aff_dtype,
+                          csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(M >= 0 && ntiles > 0 && D > 0 && aff_stride > 0 && dtype_ok(aff_dtype), "affinity_finish: bad arguments");
+  CSMOE_CHECK_ARG(M == 0 || (partial && aff), "affinity_finish: null pointer");
+  return k_affinity_finish(partial, M, ntiles, D, aff, aff_stride, aff_dtype, (hipStream_t)stream);
+}
+
 int csmoe_gate_select_ok(int T, int D, int E, int K, int dtype) {
   return T >= 0 && D > 0 && K > 0 && k_gate_select_ok(T, D, E, K, dtype, nullptr, nullptr) ? 1 : 0;
 }
@@ -286,6 +294,19 @@ int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, in
   CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "dense_gemm: ACTGRAD epilogue needs aux");
   if (M == 0) return CSMOE_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (epilogue == CSMOE_EPI_SOFTPLUS_ROWSUM || epilogue == CSMOE_EPI_SOFTPLUS_GRAD) {
+    // the affinity epilogues of the competition pass: the 256x256-tile bf16 kernel only
+    const bool rowsum = epilogue == CSMOE_EPI_SOFTPLUS_ROWSUM;
+    CSMOE_CHECK_ARG(epilogue == CSMOE_EPI_SOFTPLUS_ROWSUM || aux, "dense_gemm: SOFTPLUS_GRAD needs aux (the FP32 row scales)");
+    CSMOE_CHECK_ARG(!rowsum || ldc >= (N + 255) / 256, "dense_gemm: SOFTPLUS_ROWSUM: ldc is the row stride of the FP32 table [M, ceil(N/256)]");
+    if (dtype != CSMOE_BF16 || !gg_fast_rowspace_ok(lda, ldb, rowsum ? (int64_t)N : ldc, M, N, Kd, A, rowsum ? A : C) ||
+        ((uintptr_t)C & 15)) {
+      csmoe_set_error("dense_gemm: the affinity epilogues need bf16 operands on the fast path (dimensions multiples of 8, "
+                      "16-byte aligned, under 2 GiB)");
+      return CSMOE_ERR_UNSUPPORTED;
+    }
+    return gg8_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B, bias, st);
+  }
   if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C ? C : C2)) {
     if (use_v2_rowspace(M, N, Kd))
       return gg8_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B,

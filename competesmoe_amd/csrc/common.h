@@ -110,6 +110,18 @@ __device__ __forceinline__ float quick_gelu_grad_rounded(float x) {
 }
 
 // ------------------------------------------------------------------ wave reductions (64 lanes)
+// softplus with torch's threshold (x > 20 -> x) and its derivative.  precise: expf / log1pf as torch computes them; otherwise the
+// hardware exp / log (the values are averaged over D right after).  Shared by the affinity kernels (moe_kernels.hip) and the
+// affinity epilogues of the row-space GEMM (gemm_epilogue.h).
+__device__ __forceinline__ float softplus_rt(float x, bool precise) {
+  if (precise) return x > 20.f ? x : log1pf(expf(x));
+  return x > 20.f ? x : __logf(1.f + __expf(x));
+}
+__device__ __forceinline__ float softplus_grad_rt(float x, bool precise) {
+  if (precise) return 1.f / (1.f + expf(-x));
+  return x > 20.f ? 1.f : __frcp_rn(1.f + __expf(-x));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

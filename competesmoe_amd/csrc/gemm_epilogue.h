@@ -134,6 +134,71 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][
   }
 }
 
+// The two affinity epilogues of the competition pass: y = round(acc + bias) is staged like every other variant, then
+//   GRAD = false: each row's 256 staged columns are reduced to sum softplus(y) (8 per thread, then the 32 threads of the row by
+//                 shuffles: a fixed order) into the FP32 table C[row][column tile];
+//   GRAD = true : C[row][col] = round(g * sigmoid(y)) with g = aux[row] / N (aux: FP32 d aff, one per row), g rounded to bf16
+//                 first under flag bit 1.
+// flags (EpiArgs::act): bit 0 precise exp / log1p, bit 1 round every softplus / product to bf16 first (x.dtype tensor ops).
+template <bool GRAD>
+__device__ __forceinline__ void epi_softplus(const EpiArgs& p, const f32x4 (&acc)[4][8], char* smem, int row0, int rows, int tc0,
+                                             int wm, int wn, int lane) {
+  bf16* stg = (bf16*)smem;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int ec = (threadIdx.x & 31) * 8, er = threadIdx.x >> 5;
+  const int ncol = tc0 + ec;
+  const bool col_ok = ncol < p.NC;
+  const bool precise = p.act & 1, rnd = p.act & 2;
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && tc0 + n < p.NC) {
+      const bf16x4 b4 = *(const bf16x4*)((const bf16*)p.bias + tc0 + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = (float)b4[j];
+    }
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+      const int m = (rb >> 2) * 128 + wm * 64 + (rb & 3) * 16 + i16;
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = p.bias ? (bf16)(acc[cb][rb][j] + b[j]) : (bf16)acc[cb][rb][j];
+      *(bf16x4*)(stg + m * EPI_LD + n) = o;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const int nt = tc0 >> 8;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = er + 16 * i;                      // the two rows of a wave go through the loop together (shuffles below)
+    const bf16x8 o0 = *(const bf16x8*)(stg + r * EPI_LD + ec);
+    if constexpr (!GRAD) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float sp = softplus_rt((float)o0[j], precise);
+        s += rnd ? (float)(bf16)sp : sp;
+      }
+      if (!col_ok) s = 0.f;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+      if ((threadIdx.x & 31) == 0 && r < rows) ((float*)p.C)[(int64_t)(row0 + r) * p.ldc + nt] = s;
+    } else {
+      if (col_ok && r < rows) {
+        const float g0 = ((const float*)p.aux)[row0 + r] / (float)p.NC;          // d aff / D, as softplus_mean_bwd_kernel forms it
+        const float sc = rnd ? (float)(bf16)g0 : g0;
+        bf16x8 o1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o1[j] = (bf16)(sc * softplus_grad_rt((float)o0[j], precise));
+        *(bf16x8*)((bf16*)p.C + (int64_t)(row0 + r) * p.ldc + ncol) = o1;
+      }
+    }
+  }
+}
+
 template <int CLS>
 __device__ __forceinline__ void epi_by_act(const EpiArgs& p, const f32x4 (&acc)[4][8], char* smem, int row0, int rows, int tc0,
                                            int wm, int wn, int lane) {
@@ -147,6 +212,8 @@ __device__ __forceinline__ void rowspace_epilogue(const EpiArgs& p, const f32x4 
                                                   int tc0, int wm, int wn, int lane) {
   switch (p.epilogue) {
     case CSMOE_EPI_ACTGRAD: epi_by_act<EC_ACTGRAD>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_SOFTPLUS_ROWSUM: epi_softplus<false>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_SOFTPLUS_GRAD: epi_softplus<true>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
     case CSMOE_EPI_ROUND_BIAS32_ACT: epi_by_act<EC_R32_ACT>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
     case CSMOE_EPI_BIAS_ACT: epi_by_act<EC_BIAS_ACT>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
     case CSMOE_EPI_BIAS:

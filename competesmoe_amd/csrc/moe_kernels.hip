@@ -670,18 +670,8 @@ __global__ void __launch_bounds__(256) colsum_f32_wide_kernel(const float* G, in
 // =====================================================================================================================
 // Competition affinity: aff[r] = mean_d softplus(y[r,d])  (competesmoe.py:242) and its backward
 // =====================================================================================================================
-// softplus with torch's threshold (x > 20 -> x).  PRECISE: expf / log1pf as torch computes it; otherwise the hardware exp / log
-// (the value is averaged over D right after).
-template <bool PRECISE>
-__device__ __forceinline__ float softplusf_(float x) {
-  if constexpr (PRECISE) return x > 20.f ? x : log1pf(expf(x));
-  else return x > 20.f ? x : __logf(1.f + __expf(x));
-}
-template <bool PRECISE>
-__device__ __forceinline__ float sp_sigmoidf_(float x) {
-  if constexpr (PRECISE) return 1.f / (1.f + expf(-x));
-  else return x > 20.f ? 1.f : __frcp_rn(1.f + __expf(-x));
-}
+template <bool PRECISE> __device__ __forceinline__ float softplusf_(float x) { return softplus_rt(x, PRECISE); }
+template <bool PRECISE> __device__ __forceinline__ float sp_sigmoidf_(float x) { return softplus_grad_rt(x, PRECISE); }
 
 template <typename T> struct Vec16;
 template <> struct Vec16<bf16> { static constexpr int N = 8; typedef bf16x8 V; };
@@ -1426,6 +1416,23 @@ static void softplus_launch(const void* y, void* aff, int R, int D, bool vec, in
     if (precise) hipLaunchKernelGGL((softplus_mean_kernel<T, TA, false, true>), grid, block, 0, st, (const T*)y, (TA*)aff, R, D);
     else         hipLaunchKernelGGL((softplus_mean_kernel<T, TA, false, false>), grid, block, 0, st, (const T*)y, (TA*)aff, R, D);
   }
+}
+
+__global__ void __launch_bounds__(256) affinity_finish_kernel(const float* partial, int M, int nt, int D, void* aff, int64_t stride,
+                                                              int aff_dtype) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float s = 0.f;
+  for (int j = 0; j < nt; ++j) s += partial[(int64_t)m * nt + j];          // column tiles in ascending order: deterministic
+  s /= (float)D;
+  if (aff_dtype == CSMOE_BF16) ((bf16*)aff)[(int64_t)m * stride] = (bf16)s; else ((float*)aff)[(int64_t)m * stride] = s;
+}
+
+int k_affinity_finish(const float* partial, int M, int nt, int D, void* aff, int64_t stride, int aff_dtype, hipStream_t st) {
+  if (M == 0) return CSMOE_OK;
+  hipLaunchKernelGGL(affinity_finish_kernel, dim3((M + 255) / 256), dim3(256), 0, st, partial, M, nt, D, aff, stride, aff_dtype);
+  CSMOE_CHECK_LAUNCH("affinity_finish");
+  return CSMOE_OK;
 }
 
 int k_softplus_mean(const void* y, void* aff, int R, int D, int dtype, int aff_dtype, int precise, hipStream_t st) {

@@ -390,7 +390,7 @@ def _grouped_wgrad(a: torch.Tensor, b: torch.Tensor, bins, E: int, pd) -> torch.
     return ops.sum_partials(part.view(E * P, Na * Nb), E, P, pd).view(E, Na, Nb)
 
 
-def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool):
+def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool, dy_extra=None):
     """Returns dx2, dw, (gW1 [E,..], gb1 [E,F]|None, gW2 [E,..], gb2 [E,Dout]|None)."""
     if saved is None:
         raise RuntimeError("competesmoe_amd: the MoE layer's saved activations were freed by the first backward pass "
@@ -401,6 +401,8 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
     dev = dout.device
     E = tab.E
     dy, dw = ops.combine_bwd(dout.contiguous(), y if need_dw else None, bins, w, want_dw=need_dw, act_dtype=hact.dtype)
+    if dy_extra is not None:                # gradient of the per-slot outputs (MoEFFNModulesSlots), already in binned order
+        dy = dy + dy_extra
     ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
     ld1 = tab.D if tab.layout == L.B_NK else tab.F
     # dH = dY @ W2 (+ activation backward in the epilogue)
@@ -449,6 +451,52 @@ class MoEFFNModules(torch.autograd.Function):
         need_params = any(ctx.needs_input_grad[5:])
         dx2, dw, grads = _ffn_backward(dout, ctx.w, tab, ctx.saved, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                        need_params)
+        ctx.saved = None
+        pg: List[Optional[torch.Tensor]] = [None] * ctx.n_params
+        if grads is not None:
+            gW1, gb1, gW2, gb2 = grads
+            E = tab.E
+            seq = [gW1] + ([gb1] if gb1 is not None else []) + [gW2] + ([gb2] if gb2 is not None else [])
+            pg = [g[e] for g in seq for e in range(E)]
+        return (dx2, dw, None, None, None, *pg)
+
+
+class _SlotMap:
+    """Adapters so ops.dispatch_rows moves rows between the binned order and the flat (token, k) order of one binning."""
+    def __init__(self, index, n):
+        self.perm, self.K, self.n = index, 1, n
+
+
+class MoEFFNModulesSlots(torch.autograd.Function):
+    """MoEFFNModules that also returns the expert outputs per (token, k) slot, y_tk [T, K, Dout] -- what
+    `torch.gather(expert_outputs, 2, idx)` takes out of the dense competition pass for the diversity loss
+    (moe_model/model/moe/competesmoe.py:256-258), from the sparse step's own rows (same bits), so that the dense pass need not keep
+    its outputs (CompetitionAffinity)."""
+
+    @staticmethod
+    def forward(ctx, x2, w, idx, tab: ExpertTable, combine_mode: int, *params):
+        x2 = x2.contiguous()
+        out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, None)
+        bins, y = saved[0], saved[4]
+        y_tk = ops.dispatch_rows(y, _SlotMap(bins.slot_of, bins.n))           # y_tk[t*K+k] = y[slot_of[t*K+k]]
+        ctx.tab, ctx.saved, ctx.w = tab, saved, w
+        ctx.n_params = len(params)
+        return out, y_tk.view(x2.shape[0], idx.shape[-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dout, dy_tk):
+        tab = ctx.tab
+        if ctx.saved is None:
+            _ffn_backward(dout, ctx.w, tab, None, False, False, False)        # raises the second-backward error
+        bins = ctx.saved[0]
+        extra = None
+        if dy_tk is not None:
+            extra = ops.dispatch_rows(dy_tk.reshape(bins.n, -1).contiguous(), _SlotMap(bins.perm, bins.n))   # binned row m <- slot perm[m]
+        if dout is None:
+            dout = torch.zeros(ctx.w.shape[0], tab.Dout, dtype=ctx.saved[4].dtype, device=ctx.w.device)
+        need_params = any(ctx.needs_input_grad[5:])
+        dx2, dw, grads = _ffn_backward(dout, ctx.w, tab, ctx.saved, ctx.needs_input_grad[0], ctx.needs_input_grad[1], need_params,
+                                       dy_extra=extra)
         ctx.saved = None
         pg: List[Optional[torch.Tensor]] = [None] * ctx.n_params
         if grads is not None:
@@ -663,6 +711,76 @@ class SoftplusMean(torch.autograd.Function):
     def backward(ctx, daff):
         (y2,) = ctx.saved_tensors
         return ops.softplus_mean_bwd(y2, daff.contiguous().to(ctx.aff_dtype)), None
+
+
+class CompetitionAffinity(torch.autograd.Function):
+    """aff[t, e] = mean_d softplus(expert_e(x[t]))[d] for EVERY expert over all tokens -- the dense pass of `competition_policy`
+    (moe_model/model/moe/competesmoe.py:237-243; pretrain competesmoe.py:395-401) -- without its [T, E, D] outputs and without saved
+    activations: the second GEMM of each expert reduces softplus(y) in its epilogue (y is never stored), and the backward recomputes
+    each expert's two GEMMs, turns the recomputed y into dy = d aff / D * sigmoid(y) in the epilogue and runs the four gradient
+    GEMMs of DenseFFN.backward.  8 GEMM passes per expert instead of 6, and O(T * (F + D)) scratch instead of O(T * E * (2F + D))
+    kept alive (130 GB at 64 experts x 32k tokens x 4096 / 11008).  The K selected experts' OUTPUTS (the weighted sum, the
+    diversity loss) come from the sparse step on the same x, which produces the same bits.
+
+    params = w1_0.., [b1_0..], w2_0.., [b2_0..] (E each; biases all-or-none per group), laid out as `layout` says."""
+
+    @staticmethod
+    def forward(ctx, x2, E: int, act: int, layout: int, has_b1: bool, has_b2: bool, fp32_affinity: bool, *params):
+        x2 = x2.contiguous()
+        op = x2.dtype
+        w1 = params[:E]
+        b1 = params[E:2 * E] if has_b1 else [None] * E
+        o = 2 * E if has_b1 else E
+        w2 = params[o:o + E]
+        b2 = params[o + E:o + 2 * E] if has_b2 else [None] * E
+        T = x2.shape[0]
+        aff = torch.empty(T, E, dtype=torch.float32 if fp32_affinity else op, device=x2.device)
+        cast = lambda t: None if t is None else (t if t.dtype == op else t.to(op)).contiguous()
+        for e in range(E):
+            hact = ops.dense_gemm(x2, cast(w1[e]), layout, bias=cast(b1[e]), epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True,
+                                  want_c=False)[1]
+            ops.dense_gemm_affinity(hact, cast(w2[e]), layout, cast(b2[e]), aff[:, e], rounded=not fp32_affinity)
+        ctx.save_for_backward(x2, *params)
+        ctx.cfg = (E, act, layout, has_b1, has_b2, fp32_affinity)
+        return aff
+
+    @staticmethod
+    def backward(ctx, daff):
+        x2, *params = ctx.saved_tensors
+        E, act, layout, has_b1, has_b2, fp32_affinity = ctx.cfg
+        op = x2.dtype
+        w1 = params[:E]
+        b1 = params[E:2 * E] if has_b1 else [None] * E
+        o = 2 * E if has_b1 else E
+        w2 = params[o:o + E]
+        b2 = params[o + E:o + 2 * E] if has_b2 else [None] * E
+        cast = lambda t: None if t is None else (t if t.dtype == op else t.to(op)).contiguous()
+        daff = daff.contiguous()
+        need = ctx.needs_input_grad
+        dx = None
+        gw1, gb1, gw2, gb2 = [None] * E, [None] * E, [None] * E, [None] * E
+        for e in range(E):
+            w1o, b1o, w2o, b2o = cast(w1[e]), cast(b1[e]), cast(w2[e]), cast(b2[e])
+            hpre, hact = ops.dense_gemm(x2, w1o, layout, bias=b1o, epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True,
+                                        want_c=act != L.ACT_RELU)
+            # d aff / D is formed in the epilogue as the reference's autograd forms it: rounded to x.dtype for the LLaVA stack
+            dy = ops.dense_gemm_affinity_grad(hact, w2o, layout, b2o, daff[:, e].float().contiguous(), rounded=not fp32_affinity)
+            dh = ops.dense_gemm(dy, w2o, _flip(layout), epilogue=L.EPI_ACTGRAD, act=act, aux=hpre if hpre is not None else hact)
+            k = 7 + e
+            if need[k + o]:
+                gw2[e] = _dense_wgrad(dy, hact, w2[e].dtype) if layout == L.B_NK else _dense_wgrad(hact, dy, w2[e].dtype)
+            if has_b2 and need[k + o + E]:
+                gb2[e] = _chunked_dense_colsum(dy, b2[e].dtype)
+            if need[k]:
+                gw1[e] = _dense_wgrad(dh, x2, w1[e].dtype) if layout == L.B_NK else _dense_wgrad(x2, dh, w1[e].dtype)
+            if has_b1 and need[k + E]:
+                gb1[e] = _chunked_dense_colsum(dh, b1[e].dtype)
+            if need[0]:
+                dxe = ops.dense_gemm(dh, w1o, _flip(layout))
+                dx = dxe if dx is None else dx.add_(dxe)
+            del hpre, hact, dy, dh
+        grads = list(gw1) + (list(gb1) if has_b1 else []) + list(gw2) + (list(gb2) if has_b2 else [])
+        return (dx, None, None, None, None, None, None, *grads)
 
 
 # ======================================================================================================== diversity loss

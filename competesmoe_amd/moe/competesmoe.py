@@ -1,5 +1,7 @@
 """`competesmoe`: router policy on ordinary steps, competition policy (every expert runs densely, top-K by mean-softplus
 affinity, router distilled towards it) on scheduled steps -- moe_model/model/moe/competesmoe.py:8-415."""
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -8,7 +10,7 @@ from .. import _lib as L
 from ..functional import RouterSelect, SoftplusMean
 from ..schedule import draw_balanced_flips
 from .register import register_moe
-from .moe import MoeLayer
+from .moe import MoeLayer, parse_expert
 
 
 @register_moe("competesmoe")
@@ -82,19 +84,35 @@ class CompeteSMoE(MoeLayer):
         """competesmoe.py:219-259: every expert densely (DenseFFN kernels), affinity = mean softplus (SoftplusMean kernel),
         softmax fp32 + top-K on the RAW affinities + renormalisation in x.dtype (RouterSelect, SEL_RAW)."""
         B, N, D = x.shape
-        outs = [self.dense_expert(i, x) for i in range(self.num_of_experts)]
-        aff = torch.stack([SoftplusMean.apply(o.reshape(B * N, o.shape[-1])) for o in outs], dim=-1)      # [T,E] x.dtype
+        aff = self.dense_affinities(x) if self._lean_competition(x) else None
+        lean = aff is not None
+        if not lean:
+            outs = [self.dense_expert(i, x) for i in range(self.num_of_experts)]
+            aff = torch.stack([SoftplusMean.apply(o.reshape(B * N, o.shape[-1])) for o in outs], dim=-1)      # [T,E] x.dtype
         scores = torch.sigmoid(aff) if getattr(self.args, "norm_sigmoid", False) else aff
         if getattr(self.args, "norm_sigmoid", False):
             asm = F.softmax(aff, dim=-1, dtype=torch.float32)
             _, idx, w = RouterSelect.apply(scores, self.num_selected, L.SEL_RAW, False)
         else:
             asm, idx, w = RouterSelect.apply(scores, self.num_selected, L.SEL_RAW, False)
+        E, K = self.num_of_experts, self.num_selected
+        if lean:        # the selected experts' outputs come out of the sparse step (forward: compute_moe_slots), same bits
+            return w.view(B, N, K), idx.view(B, N, K), asm.view(B, N, E), aff.view(B, N, E), None
         expert_outputs = torch.stack(outs, dim=2)                                                   # [B,N,E,Dout]
         idx_l = idx.view(B, N, self.num_selected).long()
         topk = torch.gather(expert_outputs, 2, idx_l.unsqueeze(-1).expand(B, N, self.num_selected, expert_outputs.size(-1)))
-        E, K = self.num_of_experts, self.num_selected
         return w.view(B, N, K), idx.view(B, N, K), asm.view(B, N, E), aff.view(B, N, E), topk
+
+    def _lean_competition(self, x) -> bool:
+        """Run the dense pass without keeping its outputs / activations (functional.CompetitionAffinity: 8 GEMM passes per expert
+        instead of 6, O(T) scratch instead of O(T*E))?  CSMOE_COMPETITION_LEAN=1 / 0 forces it; default: when what the stored form
+        would keep alive -- T*E*(2F + Dout) activations -- exceeds 24 GiB."""
+        mode = os.environ.get("CSMOE_COMPETITION_LEAN", "auto")
+        if mode in ("0", "1"):
+            return mode == "1"
+        fc1, _, fc2 = parse_expert(self.experts[0])
+        T = x.shape[0] * x.shape[1]
+        return T * self.num_of_experts * (2 * fc1.weight.shape[0] + fc2.weight.shape[0]) * x.element_size() > 24 * 2 ** 30
 
     def router_loss(self, gate_softmax, affinity_softmax):
         return F.mse_loss(gate_softmax, affinity_softmax)
@@ -111,12 +129,15 @@ class CompeteSMoE(MoeLayer):
                 routerloss = routerloss + self.router_loss(
                     affinity_softmax=torch.gather(aff_softmax, -1, il).detach(),
                     gate_softmax=torch.gather(gate_softmax, -1, il)) * self.args.router_theta
+            # the reference re-runs the K selected experts from x (competesmoe.py:374-379); weights are already x.dtype
+            if expert_outputs is None:
+                output, expert_outputs = self.compute_moe_slots(aff_idx, aff_w, x, weights_rounded=True)
+            else:
+                output = self.compute_moe(aff_idx, aff_w, None, x, weights_rounded=True)
             diversity_loss = self.experts_diversity_loss(expert_outputs=expert_outputs)
             balance_loss = self.balanceloss(selected_experts=aff_idx, gate_softmax=aff_softmax)
             auxiliary_loss = (routerloss * self.args.router_loss_coef + diversity_loss * self.args.diversity_loss_coef
                               + balance_loss * self.args.bal_comp_loss_coef)
-            # the reference re-runs the K selected experts from x (competesmoe.py:374-379); weights are already x.dtype
-            output = self.compute_moe(aff_idx, aff_w, None, x, weights_rounded=True)
             infor_aux = {"balance_loss": balance_loss.clone().detach(), "diversity_loss": diversity_loss.clone().detach(),
                          "routerloss": routerloss.clone().detach()}
         else:

@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
-from ..functional import (ExpertTable, GateLogits, GateSelect, MoEFFNModules, MoEFFNModulesResidual, RouterSelect, DenseFFN, DiversityLoss,
+from ..functional import (CompetitionAffinity, ExpertTable, GateLogits, GateSelect, MoEFFNModules, MoEFFNModulesResidual,
+                          MoEFFNModulesSlots, RouterSelect, DenseFFN, DiversityLoss,
                           RouterAux)
 from .. import ops
 
@@ -261,6 +262,34 @@ class MoeLayer(nn.Module):
         else:
             out = MoEFFNModules.apply(x.reshape(B * N, D), w2.contiguous(), idx2.contiguous(), tab, mode, *params)
         return out.view(B, N, out.shape[-1])
+
+    def compute_moe_slots(self, selected_experts, weights, x, weights_rounded: bool = False):
+        """compute_moe plus the per-slot expert outputs [B, N, K, Dout] of the same pass (MoEFFNModulesSlots)."""
+        B, N, D = x.shape
+        tab, params = self._expert_table(len(self.experts), x.dtype, x.device)
+        mode = L.COMBINE_SEQ_RW if weights_rounded else L.COMBINE_SEQ
+        K = selected_experts.shape[-1]
+        idx2 = selected_experts.reshape(B * N, K).int().contiguous()
+        w2 = weights.reshape(B * N, K).float().contiguous()
+        out, y_tk = MoEFFNModulesSlots.apply(x.reshape(B * N, D), w2, idx2, tab, mode, *params)
+        return out.view(B, N, out.shape[-1]), y_tk.view(B, N, K, y_tk.shape[-1])
+
+    def dense_affinities(self, x, fp32_affinity: bool = False):
+        """[B*N, E] affinities of the dense competition pass without its outputs (CompetitionAffinity), or None when the shapes
+        are not ones its kernels take."""
+        B, N, D = x.shape
+        x2 = x.reshape(B * N, D)
+        parsed = [parse_expert(m) for m in self.experts]
+        fc1s, acts, fc2s = zip(*parsed)
+        if len(set(acts)) != 1 or not ops.affinity_ok(x2, fc1s[0].weight.shape[0], fc2s[0].weight.shape[0]):
+            return None
+        has_b1 = all(f.bias is not None for f in fc1s)
+        has_b2 = all(f.bias is not None for f in fc2s)
+        if (not has_b1 and any(f.bias is not None for f in fc1s)) or (not has_b2 and any(f.bias is not None for f in fc2s)):
+            return None
+        params = [f.weight for f in fc1s] + ([f.bias for f in fc1s] if has_b1 else []) + [f.weight for f in fc2s] \
+            + ([f.bias for f in fc2s] if has_b2 else [])
+        return CompetitionAffinity.apply(x2, len(self.experts), acts[0], L.B_NK, has_b1, has_b2, fp32_affinity, *params)
 
     def dense_expert(self, i: int, x):
         """experts[i](x) over all tokens (shared expert / competition pass)."""

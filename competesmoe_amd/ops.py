@@ -511,6 +511,48 @@ def dense_gemm(A: torch.Tensor, B: torch.Tensor, b_layout: int, bias: Optional[t
     return (Cm, C2) if want_c2 else Cm
 
 
+def affinity_ok(x2: torch.Tensor, d_ff: int, d_out: int) -> bool:
+    """Can the competition pass of one dense expert run with the affinity epilogues (csmoe_dense_gemm, SOFTPLUS_ROWSUM / _GRAD)?"""
+    T, D = x2.shape
+    return (x2.is_cuda and x2.dtype == torch.bfloat16 and D % 8 == 0 and d_ff % 8 == 0 and d_out % 8 == 0
+            and T * max(D, d_ff, d_out) * 2 < 2 ** 31 and max(D, d_ff, d_out) * max(D, d_ff, d_out) * 2 < 2 ** 31)
+
+
+def _softplus_flags(rounded: bool) -> int:
+    return (1 if SOFTPLUS_PRECISE else 0) | (2 if rounded else 0)
+
+
+def dense_gemm_affinity(h: torch.Tensor, w2: torch.Tensor, b_layout: int, bias: Optional[torch.Tensor], aff_col: torch.Tensor,
+                        rounded: bool) -> None:
+    """aff_col[t] = mean_n softplus(round(h[t] @ w2 (+ bias))[n]) without storing the product: the second GEMM of a dense expert with
+    the SOFTPLUS_ROWSUM epilogue + csmoe_affinity_finish.  `aff_col` is a (strided) column of the affinity matrix [T, E];
+    `rounded`: every softplus value is rounded to bf16 before the mean (x.dtype tensor ops, LLaVA stack)."""
+    M, Kd = h.shape
+    N = w2.shape[0] if b_layout == L.B_NK else w2.shape[1]
+    nt = (N + 255) // 256
+    part = torch.empty(M, nt, dtype=torch.float32, device=h.device)
+    with _timed("dense_gemm_affinity", 2.0 * M * N * Kd):
+        L.check(lib.csmoe_dense_gemm(h.data_ptr(), h.stride(0), w2.data_ptr(), b_layout, w2.stride(0), _ptr(bias), M, N, Kd,
+                                     part.data_ptr(), None, None, nt, L.EPI_SOFTPLUS_ROWSUM, _softplus_flags(rounded), _dt(h), 0,
+                                     _stream()), "dense_gemm(SOFTPLUS_ROWSUM)")
+    L.check(lib.csmoe_affinity_finish(part.data_ptr(), M, nt, N, aff_col.data_ptr(), aff_col.stride(0), _dt(aff_col), _stream()),
+            "affinity_finish")
+
+
+def dense_gemm_affinity_grad(h: torch.Tensor, w2: torch.Tensor, b_layout: int, bias: Optional[torch.Tensor],
+                             daff: torch.Tensor, rounded: bool) -> torch.Tensor:
+    """dy[t, n] = round(g[t] * sigmoid(round(h[t] @ w2 (+ bias))[n])), g = daff / N (rounded to bf16 first when `rounded`): the gradient
+    of dense_gemm_affinity's mean with respect to the (recomputed, never stored) expert output; daff fp32 [T] contiguous."""
+    M, Kd = h.shape
+    N = w2.shape[0] if b_layout == L.B_NK else w2.shape[1]
+    dy = torch.empty(M, N, dtype=h.dtype, device=h.device)
+    with _timed("dense_gemm_affinity_grad", 2.0 * M * N * Kd):
+        L.check(lib.csmoe_dense_gemm(h.data_ptr(), h.stride(0), w2.data_ptr(), b_layout, w2.stride(0), _ptr(bias), M, N, Kd,
+                                     dy.data_ptr(), None, daff.data_ptr(), N, L.EPI_SOFTPLUS_GRAD, _softplus_flags(rounded),
+                                     _dt(h), 0, _stream()), "dense_gemm(SOFTPLUS_GRAD)")
+    return dy
+
+
 def expert_order(offsets: torch.Tensor, E: int) -> torch.Tensor:
     order = torch.empty(8 * ((E + 7) // 8) + 1, dtype=torch.int32, device=offsets.device)
     L.check(lib.csmoe_expert_order(offsets.data_ptr(), E, order.data_ptr(), _stream()), "expert_order")

@@ -69,6 +69,17 @@ enum {
                               the pretrain stack's `scores = cvmm(...) + bias[sel]` under autocast -- the cvmm output is already
                               rounded to bf16, the fp32 master bias promotes the sum to fp32, the activation runs on that and the
                               next cvmm rounds once more (moe_pretrain_model/layers/moe/moe.py:400-405) */
+  ,
+  /* The competition pass without its [T,E,D] outputs (csmoe_dense_gemm only, bf16 fast path; `act` carries two flags: bit 0 =
+   * precise expf / log1pf, bit 1 = every softplus value / the row scale's product is rounded to bf16 as x.dtype tensor ops do):
+   *   SOFTPLUS_ROWSUM: y = round(acc + bias[n]) is never stored; C is an FP32 table [M, ceil(N/256)] (ldc = its row stride) that
+   *                    receives sum_n softplus(y[m,n]) over each 256-column tile -- `torch.mean(F.softplus(expert(x)), dim=-1)`
+   *                    (moe_model/model/moe/competesmoe.py:240-243) is the row sum of that table over D (csmoe_affinity_finish);
+   *   SOFTPLUS_GRAD:   C[m,n] = round(g[m] * sigmoid(y[m,n])), g[m] = aux[m] / N (rounded to bf16 under bit 1) with aux an FP32
+   *                    vector [M] = d affinity[m]: the gradient of that mean with respect to y, from a recomputed y (autograd of
+   *                    the same lines). */
+  CSMOE_EPI_SOFTPLUS_ROWSUM = 5,
+  CSMOE_EPI_SOFTPLUS_GRAD = 6
 };
 
 int csmoe_version(void);
@@ -126,6 +137,11 @@ int csmoe_gate_select_rows(void);
 int csmoe_gate_select(const void* x, const void* w_gate, int T, int D, int E, int K, int sel_mode, int round_sum_bf16,
                       float sel_param, int dtype, void* logits, float* softmax, int32_t* idx, float* w, int32_t* block_hist,
                       csmoe_stream_t stream);
+
+/* aff[m] = (sum_j partial[m, j]) / D in `aff_dtype` (bf16 or fp32): closes CSMOE_EPI_SOFTPLUS_ROWSUM; `aff` is strided
+ * (element stride `aff_stride`) so that expert e's column of an affinity matrix [T, E] is written in place. */
+int csmoe_affinity_finish(const float* partial, int M, int ntiles, int D, void* aff, int64_t aff_stride, int aff_dtype,
+                          csmoe_stream_t stream);
 
 /* ---- dispatch / combine ------------------------------------------------------------------------------
  * dispatch: xs[m,:] = x[perm[m] / K, :]                      (gather of x rows, moe.py:201 `x[batch_idx, token_idx]`;

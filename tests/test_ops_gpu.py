@@ -739,3 +739,71 @@ def test_smoe_layer_fused_router_equals_two_launch_router(monkeypatch):
         assert torch.allclose(a[1], b[1], rtol=1e-3, atol=1e-5)
         assert torch.allclose(a[2], b[2], rtol=5e-2, atol=5e-3 * b[2].abs().max().item())
         assert torch.allclose(a[3], b[3], rtol=5e-2, atol=5e-3 * b[3].abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ competition pass without its outputs
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,F,Dout,bias", [(300, 512, 256, True), (2100, 1024, 520, False), (64, 256, 264, True)])
+@pytest.mark.parametrize("rounded", [True, False])
+def test_affinity_epilogues_match_gemm_then_softplus_mean(T, F, Dout, bias, rounded):
+    """SOFTPLUS_ROWSUM / SOFTPLUS_GRAD epilogues of csmoe_dense_gemm against the stored form: y = dense_gemm (+bias), then the
+    softplus_mean kernels.  Same rounded y, same softplus values; the row sums are added in another order (column tiles), so the
+    affinities agree to fp32 rounding (1 ulp of the affinity dtype) and the gradient to 1 bf16 ulp."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(T + F)
+    h = torch.randn(T, F, device=dev, generator=g).to(torch.bfloat16)
+    w2 = (torch.randn(Dout, F, device=dev, generator=g) * F ** -0.5 * 2).to(torch.bfloat16)
+    b2 = (torch.randn(Dout, device=dev, generator=g) * 0.1).to(torch.bfloat16) if bias else None
+    y = ops.dense_gemm(h, w2, L.B_NK, bias=b2, epilogue=L.EPI_BIAS if bias else L.EPI_PLAIN)
+    adt = torch.bfloat16 if rounded else torch.float32
+    ref = ops.softplus_mean(y, adt)
+    aff = torch.empty(T, 3, dtype=adt, device=dev)
+    ops.dense_gemm_affinity(h, w2, L.B_NK, b2, aff[:, 1], rounded=rounded)
+    got = aff[:, 1]
+    tol = 2.0 ** -7 if rounded else 2e-6
+    assert ((got.float() - ref.float()).abs() <= tol * ref.float().abs()).all()
+    if rounded:
+        assert (got != ref).float().mean().item() <= 0.01            # a bf16 rounding boundary now and then
+    daff = torch.randn(T, device=dev, generator=g).to(adt)
+    ref_dy = ops.softplus_mean_bwd(y, daff)
+    dy = ops.dense_gemm_affinity_grad(h, w2, L.B_NK, b2, daff.float().contiguous(), rounded)
+    assert torch.equal(dy, ref_dy)
+
+
+@pytest.mark.gpu
+def test_competesmoe_lean_competition_equals_stored_competition(monkeypatch):
+    """LLaVA `competesmoe` on a competition step with CSMOE_COMPETITION_LEAN=1 (affinities from the GEMM epilogue, no dense outputs
+    kept, backward by recomputation, selected outputs from the sparse step) against the stored form: same routing up to affinity
+    ties, same losses / outputs / gradients to bf16 rounding."""
+    import types
+    import torch.nn as nn
+    from competesmoe_amd.moe.competesmoe import CompeteSMoE
+    dev = "cuda"
+    torch.manual_seed(11)
+    D, F, E, K = 256, 512, 4, 2
+    args = types.SimpleNamespace(rate_flip=1.0, warm_up=0.0, max_compete_in_iter=1, balance_loss_coef=0.01, router_z_loss_coef=0.001,
+                                 router_loss_coef=0.1, diversity_loss_coef=0.1, bal_comp_loss_coef=0.05, router_theta=0.5)
+    layer = CompeteSMoE(D, D, E, K, nn.Sequential(nn.Linear(D, F), nn.GELU(), nn.Linear(F, D)), args).to(dev).to(torch.bfloat16)
+    layer.set_total_steps(4, 0, {})
+    layer.prob_flips.fill_(True)             # every step competes
+    layer._flips_host = None
+    layer.set_current_steps(1)
+    x = (torch.randn(2, 160, D, device=dev) * 0.7).to(torch.bfloat16)
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CSMOE_COMPETITION_LEAN", flag)
+        xi = x.clone().requires_grad_(True)
+        layer.zero_grad(set_to_none=True)
+        assert layer._competing(xi)
+        out, aux, _, info = layer(xi)
+        (out.float().pow(2).mean() + aux.float()).backward()
+        grads = torch.cat([p.grad.float().flatten() for p in layer.parameters() if p.grad is not None])
+        res.append((out.detach().float(), aux.detach().float(), xi.grad.float(), grads, {k: float(v) for k, v in info.items()}))
+    a, b = res
+    assert set(a[4]) == set(b[4]) and "diversity_loss" in a[4]
+    same = ((a[0] - b[0]).abs().amax(-1) <= 0.02 * a[0].abs().amax()).float().mean().item()
+    assert same >= 0.97, same                                       # rows routed differently only on affinity ties
+    for k in a[4]:
+        assert abs(a[4][k] - b[4][k]) <= 2e-2 * max(abs(a[4][k]), 1e-3), (k, a[4][k], b[4][k])
+    assert (a[2] - b[2]).abs().mean() <= 0.05 * a[2].abs().mean()
+    assert (a[3] - b[3]).abs().mean() <= 0.05 * a[3].abs().mean()
