@@ -72,11 +72,15 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   int e, row0 = 0, rows = 0, tr0 = 0, tc0 = 0, red_len;
   const int nct = (p.NC + BN2 - 1) / BN2;
   if (MODE == 0) {
-    const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BM2, nct, lane);
-    if ((int)blockIdx.x >= total) return;
-    const int v = xcd_remap(blockIdx.x, total);
     TilePos tp;
-    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM2, nct, v, lane, tp)) return;
+    if (p.tile_classes) {                                    // CSMOE_TILE_CLASSES=1 (A/B): full tiles first, remainder tiles last (common.h)
+      if (!grouped_find_tile_classes(p.offsets, p.E, p.single_M, BM2, nct, blockIdx.x, lane, tp)) return;
+    } else {
+      const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BM2, nct, lane);
+      if ((int)blockIdx.x >= total) return;
+      const int v = xcd_remap(blockIdx.x, total);
+      if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM2, nct, v, lane, tp)) return;
+    }
     e = tp.e;
     row0 = tp.o0 + tp.mt * BM2; rows = min(BM2, tp.o1 - row0);
     tc0 = tp.nt * BN2;
@@ -202,7 +206,64 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   const bool act3 = rows_here > 128 && cols_here > 128;    // C_hi x R_hi
   const bool act4 = rows_here > 128 && cols_here > 0;      // C_lo x R_hi
 
-  if constexpr (SCHED == BAL) {
+  // Tiles of at most 128 rows (the remainder tile of an expert: with ~1024 +- 32 rows per expert every other expert has one of
+  // 1..60 rows) only ever use the row image RL: a K-tile is ONE phase (C_all x R_lo), three images to fetch (6 of the 8 pieces per
+  // wave) and two barriers instead of four.  In the full-tile loops such a tile ran 70-83 % as long as a 256-row tile
+  // (tools/tile_stamps.py: the loop is paced by the DMA issue and the barriers, not by the MFMAs it skips); CSMOE_THIN_LOOP=0
+  // sends them through the full-tile loop again (A/B).
+  if (MODE == 0 && rows <= 128 && p.thin_loop) {
+    const bool rlo = rows_here > 0, clo = cols_here > 0, chi = cols_here > 128;
+    ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(0); ISSUE_CL(1); ISSUE_CH(1); ISSUE_RL(1);
+    WAIT_DMA(6);                                           // K-tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < nk; ++s) {
+      const char* base = smem + (s & 1) * (4 * TILE_B);
+      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B;
+      bf16x8 fc[4][2], fr[4][2];
+      if (rlo && clo) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
+      }
+      if (rlo && chi) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
+      }
+      PHASE_SYNC_IN();                                     // every wave's reads of this slot are retired: it may be re-filled
+      __builtin_amdgcn_s_setprio(0);
+      ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (rlo && clo) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+      }
+      if (rlo && chi) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 2; cb < 4; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+      }
+      WAIT_DMA(6);                                         // K-tile s+1 landed (s+2 stays in flight)
+      PHASE_SYNC_OUT();
+    }
+  } else if constexpr (SCHED == BAL) {
     // WIDE with the work of the two phases cut by ROW image instead of by column image, so that the LDS reads and the DMA issue
     // are spread over both phases (WIDE reads 20 fragments in phase A and 4 in phase B):
     //     phase A: read CL, CH, RL(s)  (16 fragments)   issue RH(s+1)            vmcnt(8)   MFMA C_all x R_lo
@@ -635,6 +696,12 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
   p.single_M = M; p.single_B = single_B; p.single_bias = single_bias;
   p.R = A; p.ld_r = lda; p.c_ptrs_in = b_ptrs; p.ld_c = ldb; p.bias_ptrs = bias_ptrs; p.offsets = offsets; p.E = E;
   p.NC = N; p.Kd = Kd; p.C = C; p.C2 = C2; p.aux = aux; p.ldc = ldc; p.epilogue = epilogue; p.act = act;
+  {
+    static const int thin = [] { const char* e = getenv("CSMOE_THIN_LOOP"); return e ? atoi(e) : 1; }();
+    p.thin_loop = thin;
+    static const int classes = [] { const char* e = getenv("CSMOE_TILE_CLASSES"); return e ? atoi(e) : 0; }();
+    p.tile_classes = classes;
+  }
   int nct = (N + BN2 - 1) / BN2;
   int64_t grid = (int64_t)nct * ((M + BM2 - 1) / BM2 + E);
   if (grid <= 0) return CSMOE_OK;
