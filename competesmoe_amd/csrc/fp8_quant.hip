@@ -123,6 +123,9 @@ __global__ void __launch_bounds__(256) quant_cols_kernel(const void* const* x_pt
 // the 128 (row, 32-column block) pairs and the 128 columns (one 32-row block each) are quantised by one thread each straight from
 // LDS -- rows by ds_read_b128 along the row, columns by ds_read_b32 down the column (consecutive lanes = consecutive banks) -- and
 // every output leaves as 16-byte stores.  6 B of HBM traffic per element with fp32 masters (4 read + 2 written).
+// Tried and dropped (gpurun_out r2x): a 128 x 128 tile (128-byte runs of the transposed copy, 16 loads in flight per thread, 66 KiB
+// of LDS = 2 workgroups per CU): 5.49 ms against 4.50 ms per call -- the load / quantise phases of a workgroup do not overlap, so the
+// eight resident workgroups of the small tile are what keeps HBM busy.
 constexpr int QB_R = 32, QB_C = 128, QB_LD = QB_C + 4;       // +4 floats: rows 16 B apart in bank space (b128 row reads)
 
 template <typename T>
