@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0
 ROUND = "r02"                    # profiles/<ROUND>/traffic.json holds the PMC pass of THIS round's kernels (see traffic_for)
 
 
-GEMM_SOURCES = ("gemm_bf16_v2.hip", "gemm_bf16_v2p.hip", "gemm_tiles.h", "common.h")    # the grouped-GEMM kernels the traffic is quoted for
+GEMM_SOURCES = ("gemm_bf16_v2.hip", "gemm_bf16_v2p.hip", "gemm_tiles.h", "gemm_epilogue.h", "common.h")    # the grouped-GEMM kernels the traffic is quoted for
 
 
 def kernel_sources_hash():
