@@ -272,7 +272,11 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
     // the same wait one hardware barrier later), and a slot is re-filled in the phase after the one that read it.  Issue order
     // ... [CL,CH,RL](s+1) | RH(s+1) | [CL,CH,RL](s+2) | RH(s+2) ...: vmcnt(8) in A leaves {[CL,CH,RL](s+1), RH(s+1)} in flight
     // (RH(s) landed), vmcnt(8) in B leaves {RH(s+1), [CL,CH,RL](s+2)} ([CL,CH,RL](s+1) landed).
+#ifdef CSMOE_DMA_ONLY     // diagnostic: the loop's DMA stream and barriers alone (no fragment reads, no MFMAs)
+    const bool rlo = false, rhi = false, clo = cols_here > 0, chi = cols_here > 128;
+#else
     const bool rlo = rows_here > 0, rhi = rows_here > 128, clo = cols_here > 0, chi = cols_here > 128;
+#endif
     ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(0); ISSUE_RH(0); ISSUE_CL(1); ISSUE_CH(1); ISSUE_RL(1);
     WAIT_DMA(8);                                           // CL, CH, RL(0) landed
     __builtin_amdgcn_s_barrier();
