@@ -390,8 +390,8 @@ class EPSMoeLayer(MoeLayer):
 
     def forward(self, x, return_id_experts=False, is_vision=False):
         B, N, D = x.shape
-        gate_logits = self.gate_logits(x)
-        weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
+        route = self._route(x)            # one-pass router where the shapes allow (its histogram feeds the GLOBAL binning below)
+        gate_logits, weights, selected_experts, gate_softmax = route.logits, route.w, route.idx, route.softmax
         tab, params = self._expert_table(len(self.experts), x.dtype, x.device)
         chunks = self._n_chunks()
         w2 = weights.reshape(B * N, weights.shape[-1]).contiguous()
@@ -524,8 +524,8 @@ class EPCompeteSMoE(MoeLayer):
 
     def forward(self, x, return_id_experts=False, is_vision=False):
         import torch.nn.functional as F
-        gate_logits = self.gate_logits(x)
-        gate_w, gate_idx, gate_softmax = self.topk_expert(gate_logits=gate_logits)
+        route = self._route(x)
+        gate_logits, gate_w, gate_idx, gate_softmax = route.logits, route.w, route.idx, route.softmax
         auxiliary_loss, infor_aux = x.new_zeros(()), {}
         if self._single._competing(self, x):
             aff_w, aff_idx, aff_softmax, _ = self.competition_policy(x)

@@ -76,9 +76,8 @@ class CompeteSMoE(MoeLayer):
 
     # ------------------------------------------------------------------ policies
     def router_policy(self, x):
-        gate_logits = self.gate_logits(x)
-        weights, selected_experts, gate_softmax = self.topk_expert(gate_logits=gate_logits)
-        return weights, selected_experts, gate_softmax, gate_logits
+        r = self._route(x)                # gate + softmax + top-K (+ binning histogram) in one launch where the shapes allow
+        return r.w, r.idx, r.softmax, r.logits
 
     def competition_policy(self, x):
         """competesmoe.py:219-259: every expert densely (DenseFFN kernels), affinity = mean softplus (SoftplusMean kernel),
