@@ -17,7 +17,9 @@
 //     pre-cast bf16 weights, the step 41.0 ms against 41.8 ms with the two cast passes -- a net 2 %, because the conversion's issue work
 //     (8 loads, 16 cvt, 4 ds_write_b128 per wave and K-tile) sits in the read sections between the barriers, not under the MFMAs.  A
 //     row-cut (BAL) variant with the quads fetched TWO phases ahead (32 staging VGPRs) was bit-identical too and SLOWER (8.17 ms): load
-//     latency is not what costs; next step = interleave that issue work into the MFMA sections (sched_group_barrier);
+//     latency is not what costs.  What costs is the vector-memory stream itself: 8 fp32 quads + 4 row pieces per wave and K-tile are 12
+//     instructions and 96 KiB per CU where the bf16 kernel has 8 and 64 KiB, and the bf16 loop is already paced by that stream
+//     (DESIGN.md section 3, round-2 stamps: the DMA stream alone takes 1.21 us of a 1.7 us K-tile);
 //   * the tiles of an expert's FIRST row tile also store the converted pieces to a bf16 copy of the weights (`b_copy`), which the two
 //     backward GEMMs of the step read through the plain LDS-DMA kernels -- experts without rows write nothing and are read by nobody.
 #include "gemm_epilogue.h"
