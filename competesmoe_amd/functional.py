@@ -622,11 +622,12 @@ class MoEFFNPacked(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def _backward(ctx, dout, dy_extra=None):
+        """(dx2, dw, gk, gv, gb, gob) -- shared with MoEFFNPackedSlots, whose per-slot output gradient arrives as `dy_extra`."""
         tab = ctx.tab
         need_params = ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
         dx2, dw, grads = _ffn_backward(dout, ctx.w, tab, ctx.saved, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                       need_params)
+                                       need_params, dy_extra=dy_extra)
         ctx.saved = None
         gk = gv = gb = gob = None
         if grads is not None:
@@ -635,7 +636,38 @@ class MoEFFNPacked(torch.autograd.Function):
                 gb = gb1 if gb1.dtype == ctx.bias_dtype else gb1.to(ctx.bias_dtype)
         if ctx.has[1] and ctx.needs_input_grad[6]:
             gob = _chunked_dense_colsum(dout.contiguous(), ctx.ob_dtype)
+        return dx2, dw, gk, gv, gb, gob
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx2, dw, gk, gv, gb, gob = MoEFFNPacked._backward(ctx, dout)
         return dx2, dw, None, gk, gv, gb, gob, None, None, (dout if (ctx.has_residual and ctx.needs_input_grad[9]) else None), None
+
+
+class MoEFFNPackedSlots(torch.autograd.Function):
+    """MoEFFNPacked that also returns the expert outputs per (token, k) slot, [T, K, Dout]: the `topk` outputs the pretrain
+    competition step takes out of its dense pass for the diversity loss (moe_pretrain_model/layers/moe/competesmoe.py:403-410), from
+    the sparse step's own rows -- so that the dense pass need not keep its outputs (CompetitionAffinityPacked)."""
+
+    @staticmethod
+    def forward(ctx, x2, w, idx, keys, values, bias, o_bias, act: int, combine_mode: int):
+        out = MoEFFNPacked.forward(ctx, x2, w, idx, keys, values, bias, o_bias, act, combine_mode, None, None)
+        bins, y = ctx.saved[0], ctx.saved[4]
+        y_tk = ops.dispatch_rows(y, _SlotMap(bins.slot_of, bins.n))
+        return out, y_tk.view(w.shape[0], idx.shape[-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dout, dy_tk):
+        if ctx.saved is None:
+            _ffn_backward(dout, ctx.w, ctx.tab, None, False, False, False)    # raises the second-backward error
+        bins = ctx.saved[0]
+        extra = None
+        if dy_tk is not None:
+            extra = ops.dispatch_rows(dy_tk.reshape(bins.n, -1).contiguous(), _SlotMap(bins.perm, bins.n))
+        if dout is None:
+            dout = torch.zeros(ctx.w.shape[0], ctx.tab.Dout, dtype=ctx.saved[4].dtype, device=ctx.w.device)
+        dx2, dw, gk, gv, gb, gob = MoEFFNPacked._backward(ctx, dout, extra)
+        return dx2, dw, None, gk, gv, gb, gob, None, None
 
 
 # ======================================================================================================== dense FFN
@@ -781,6 +813,53 @@ class CompetitionAffinity(torch.autograd.Function):
             del hpre, hact, dy, dh
         grads = list(gw1) + (list(gb1) if has_b1 else []) + list(gw2) + (list(gb2) if has_b2 else [])
         return (dx, None, None, None, None, None, None, *grads)
+
+
+class CompetitionAffinityPacked(torch.autograd.Function):
+    """CompetitionAffinity for PACKED experts keys [E, D, F] / values [E, F, Dout] (pretrain stack, `competition_policy_mlp_faster`,
+    moe_pretrain_model/layers/moe/competesmoe.py:395-401: relu(x @ keys[e]) @ values[e], no biases): same epilogues, same recompute
+    backward; the gradients are written expert by expert into packed tensors, so autograd never slices the parameters."""
+
+    @staticmethod
+    def forward(ctx, x2, keys, values, act: int, fp32_affinity: bool):
+        x2 = x2.contiguous()
+        op = x2.dtype
+        E = keys.shape[0]
+        aff = torch.empty(x2.shape[0], E, dtype=torch.float32 if fp32_affinity else op, device=x2.device)
+        for e in range(E):
+            k_e = keys[e] if keys.dtype == op else keys[e].to(op)
+            v_e = values[e] if values.dtype == op else values[e].to(op)
+            hact = ops.dense_gemm(x2, k_e.contiguous(), L.B_KN, epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True, want_c=False)[1]
+            ops.dense_gemm_affinity(hact, v_e.contiguous(), L.B_KN, None, aff[:, e], rounded=not fp32_affinity)
+        ctx.save_for_backward(x2, keys, values)
+        ctx.cfg = (act, fp32_affinity)
+        return aff
+
+    @staticmethod
+    def backward(ctx, daff):
+        x2, keys, values = ctx.saved_tensors
+        act, fp32_affinity = ctx.cfg
+        op = x2.dtype
+        E = keys.shape[0]
+        daff = daff.contiguous()
+        gk = torch.empty_like(keys) if ctx.needs_input_grad[1] else None
+        gv = torch.empty_like(values) if ctx.needs_input_grad[2] else None
+        dx = None
+        for e in range(E):
+            k_e = (keys[e] if keys.dtype == op else keys[e].to(op)).contiguous()
+            v_e = (values[e] if values.dtype == op else values[e].to(op)).contiguous()
+            hpre, hact = ops.dense_gemm(x2, k_e, L.B_KN, epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True, want_c=act != L.ACT_RELU)
+            dy = ops.dense_gemm_affinity_grad(hact, v_e, L.B_KN, None, daff[:, e].float().contiguous(), rounded=not fp32_affinity)
+            dh = ops.dense_gemm(dy, v_e, _flip(L.B_KN), epilogue=L.EPI_ACTGRAD, act=act, aux=hpre if hpre is not None else hact)
+            if gv is not None:
+                gv[e] = _dense_wgrad(hact, dy, values.dtype)
+            if gk is not None:
+                gk[e] = _dense_wgrad(x2, dh, keys.dtype)
+            if ctx.needs_input_grad[0]:
+                dxe = ops.dense_gemm(dh, k_e, _flip(L.B_KN))
+                dx = dxe if dx is None else dx.add_(dxe)
+            del hpre, hact, dy, dh
+        return dx, gk, gv, None, None
 
 
 # ======================================================================================================== diversity loss

@@ -5,7 +5,8 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from .. import _lib as L
-from ..functional import DenseFFN, DiversityLoss, RouterSelect, SoftplusMean
+from .. import ops
+from ..functional import CompetitionAffinityPacked, DenseFFN, DiversityLoss, RouterSelect, SoftplusMean
 from .moe import MoE, op_dtype
 from ..schedule import draw_balanced_flips
 from .register import register_moe
@@ -98,6 +99,13 @@ class CompeteSMoE(MoE):
         B, N, D = x.shape
         op = op_dtype(x)
         x2 = x.reshape(-1, D).to(op)
+        if self._lean_competition(x2):
+            # without the [T, E, D] outputs: affinities from the second GEMM's epilogue, backward by recomputation, the selected
+            # experts' outputs from the sparse step (forward below); functional.CompetitionAffinityPacked
+            fp32_aff = op == torch.bfloat16 and torch.is_autocast_enabled("cuda")
+            aff = CompetitionAffinityPacked.apply(x2, self.keys, self.values, self.act_code, fp32_aff)
+            asm, idx, w = RouterSelect.apply(aff, self.num_selected, L.SEL_RAW, False)
+            return w.view(B, N, -1), idx.view(B, N, -1), asm.view(B, N, -1), aff.view(B, N, -1), None
         outs = [DenseFFN.apply(x2, self.keys[e], None, self.values[e], None, self.act_code, L.B_KN) for e in range(self.n_experts)]
         # under CUDA autocast F.softplus is an fp32-policy op: fp32 softplus / mean / affinities from the bf16 expert outputs, top-K
         # and the renormalised weights on fp32 scores (the reference trains this way, simple_task.py:295); outside autocast the ops
@@ -109,6 +117,20 @@ class CompeteSMoE(MoE):
         idx_l = idx.view(B, N, -1).long()
         topk = torch.gather(eo, 2, idx_l.unsqueeze(-1).expand(B, N, self.num_selected, eo.size(-1)))
         return w.view(B, N, -1), idx.view(B, N, -1), asm.view(B, N, -1), aff.view(B, N, -1), topk
+
+    def _lean_competition(self, x2) -> bool:
+        """The dense pass without its stored outputs / activations?  CSMOE_COMPETITION_LEAN=1 / 0 forces it; default: when the
+        stored form would keep more than 24 GiB alive (T * E * (2F + Dout) activations).  Needs the plain sparse step for the
+        selected outputs (no fp8 experts, no residual handed in by the block)."""
+        import os
+        E, D, Fd = self.keys.shape
+        Dout = self.values.shape[2]
+        if self.fp8_experts or self._residual is not None or not ops.affinity_ok(x2, Fd, Dout):
+            return False
+        mode = os.environ.get("CSMOE_COMPETITION_LEAN", "auto")
+        if mode in ("0", "1"):
+            return mode == "1"
+        return x2.shape[0] * E * (2 * Fd + Dout) * x2.element_size() > 24 * 2 ** 30
 
     def router_loss(self, gate_softmax, affinity_softmax):
         return F.mse_loss(gate_softmax, affinity_softmax)
@@ -137,7 +159,10 @@ class CompeteSMoE(MoE):
         gate_weights, gate_selected_experts, gate_softmax, gate_logits = self.router_policy(x)
         if is_comp:
             aw, aidx, asm, aff, expert_outputs = self.competition_policy_mlp_faster(x)
-            out = self.compute_moe_main(x, aidx, aw)
+            if expert_outputs is None:
+                out, expert_outputs = self.ffn_slots(x, aidx, aw)
+            else:
+                out = self.compute_moe_main(x, aidx, aw)
             div = self.experts_diversity_loss(expert_outputs)
             self.add_reg(lambda: div * a.balance_loss_coef_comp / 2, self.name_moe + "_comp_diver_loss")
             if a.balance_affinity:

@@ -18,7 +18,8 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from .. import ops
-from ..functional import DenseFFN, DenseFFNFP8, GateLogits, GateSelect, MoEFFNPacked, MoEFFNPackedFP8, RouterSelect
+from ..functional import (DenseFFN, DenseFFNFP8, GateLogits, GateSelect, MoEFFNPacked, MoEFFNPackedFP8, MoEFFNPackedSlots,
+                          RouterSelect)
 from .framework_layers import LoggingLayer, OncePerIterLayer, RegularizedLayer
 
 
@@ -196,6 +197,19 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
                 h = stats["hact"]
                 self.log("relu_pass_rate", (h > 0).float().sum() / h.numel())
         return out.view(*shp[:-1], -1)
+
+    def ffn_slots(self, x, selected_experts, weights):
+        """ffn() plus the selected experts' outputs per (token, k) slot [..., K, Dout] of the same pass (MoEFFNPackedSlots)."""
+        shp = x.shape
+        op = op_dtype(x)
+        x2 = x.reshape(-1, shp[-1]).to(op)
+        K = selected_experts.shape[-1]
+        wk = weights.reshape(-1, K)
+        if op == torch.bfloat16:
+            wk = wk.to(op)
+        out, y_tk = MoEFFNPackedSlots.apply(x2, wk.float().contiguous(), selected_experts.reshape(-1, K).int().contiguous(),
+                                            self.keys, self.values, self.bias, None, self.act_code, L.COMBINE_DOT)
+        return out.view(*shp[:-1], -1), y_tk.view(*shp[:-1], K, -1)
 
     def shared_ffn(self, x, keys_shared, values_shared, bias_shared=None):
         """The always-on shared expert: the reference routes every token to expert 0 of a 1-expert table with unit weight

@@ -261,3 +261,24 @@ def test_operand_weight_cache_skips_casts_until_the_weights_change():
     finally:
         Fn.weight_cache(False)
     assert not Fn._WEIGHT_CACHE
+
+
+@pytest.mark.parametrize("case", ["competesmoe_comp", "competesmoe_comp_hybrid", "competesmoe_comp_intopk", "competesmoe_comp_tribrid"])
+def test_pretrain_competition_without_stored_outputs_matches_golden(case, monkeypatch):
+    """The same bf16 goldens (the reference run under CUDA-autocast rules with its own Triton kernels) through the competition pass
+    that keeps neither the dense outputs nor their activations (CSMOE_COMPETITION_LEAN=1: CompetitionAffinityPacked + MoEFFNPackedSlots):
+    same tolerances as the stored form."""
+    import os
+    from competesmoe_amd import functional as Fn
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", f"pretrain_{case}_bf16.pt")):
+        pytest.skip("no such golden")
+    calls = []
+    orig = Fn.CompetitionAffinityPacked.forward
+
+    def spy(ctx, *a):
+        calls.append(1)
+        return orig(ctx, *a)
+    monkeypatch.setattr(Fn.CompetitionAffinityPacked, "forward", staticmethod(spy))
+    monkeypatch.setenv("CSMOE_COMPETITION_LEAN", "1")
+    test_pretrain_layer_matches_golden(case, "bf16")
+    assert calls, "the lean competition pass was not taken"
