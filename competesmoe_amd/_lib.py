@@ -23,6 +23,7 @@ SEL_SOFTMAX, SEL_RAW, SEL_TOPK_SOFTMAX, SEL_SIGMOID, SEL_TOPK_SIGMOID = 0, 1, 2,
 COMBINE_SEQ, COMBINE_DOT, COMBINE_SEQ_RW = 0, 1, 2
 B_NK, B_KN = 0, 1
 EPI_PLAIN, EPI_BIAS, EPI_BIAS_ACT, EPI_ACTGRAD, EPI_ROUND_BIAS32_ACT, EPI_SOFTPLUS_ROWSUM, EPI_SOFTPLUS_GRAD = 0, 1, 2, 3, 4, 5, 6
+EPI_ACTGRAD_ROWSCALE = 7
 
 ACT_CODES = {"none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU, "gelu_tanh": ACT_GELU_TANH, "silu": ACT_SILU,
              "quick_gelu": ACT_QUICK_GELU}
@@ -39,6 +40,7 @@ SIGNATURES = {
     "csmoe_router_select_bwd": (_i, [_p, _i, _i, _i, _i, _i, _i, C.c_float, _p, _p, _p, _p, _p, _p, _p]),
     "csmoe_bin_workspace_bytes": (_l, [_i, _i]),
     "csmoe_bin_tokens": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "csmoe_grouped_gemm_rowdot_cols": (_i, [_i, _i, _i, _l, _l, _l, _i]),
     "csmoe_affinity_finish": (_i, [_p, _i, _i, _i, _p, _l, _i, _p]),
     "csmoe_bin_tokens_hist": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "csmoe_gate_select_ok": (_i, [_i, _i, _i, _i, _i]),

@@ -269,9 +269,13 @@ int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, in
   CSMOE_CHECK_ARG(dtype_ok(dtype), "grouped_gemm: bad dtype %d", dtype);
   CSMOE_CHECK_ARG(E > 0 && M >= 0 && N > 0 && Kd > 0, "grouped_gemm: bad shape E=%d M=%d N=%d Kd=%d", E, M, N, Kd);
   CSMOE_CHECK_ARG(b_layout == CSMOE_B_NK || b_layout == CSMOE_B_KN, "grouped_gemm: bad B layout %d", b_layout);
-  CSMOE_CHECK_ARG(epilogue >= 0 && epilogue <= 4 && act >= 0 && act <= 5, "grouped_gemm: bad epilogue/act");
+  CSMOE_CHECK_ARG(((epilogue >= 0 && epilogue <= 4) || epilogue == CSMOE_EPI_ACTGRAD_ROWSCALE) && act >= 0 && act <= 5,
+                  "grouped_gemm: bad epilogue/act");
   CSMOE_CHECK_ARG(b_ptrs && offsets && (M == 0 || (A && (C || ((epilogue == CSMOE_EPI_BIAS_ACT || epilogue == CSMOE_EPI_ROUND_BIAS32_ACT) && C2)))), "grouped_gemm: null pointer");
-  CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "grouped_gemm: ACTGRAD epilogue needs aux");
+  CSMOE_CHECK_ARG(M == 0 || (epilogue != CSMOE_EPI_ACTGRAD && epilogue != CSMOE_EPI_ACTGRAD_ROWSCALE) || aux,
+                  "grouped_gemm: ACTGRAD epilogue needs aux");
+  CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD_ROWSCALE || (C && C2),
+                  "grouped_gemm: ACTGRAD_ROWSCALE takes its FP32 row scales [M] in the C2 slot");
   CSMOE_CHECK_ARG(lda >= Kd && ldc >= N && ldb >= (b_layout == CSMOE_B_NK ? Kd : N), "grouped_gemm: leading dimension too small");
   if (M == 0) return CSMOE_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -284,6 +288,14 @@ int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, in
   }
   return gg_generic_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
                              dtype, nullptr, nullptr, st);
+}
+
+int csmoe_grouped_gemm_rowdot_cols(int M, int N, int Kd, int64_t lda, int64_t ldb, int64_t ldc, int dtype) {
+  // partial sums per row that CSMOE_EPI_ACTGRAD_ROWSCALE writes into its dot table for this launch shape (16-byte aligned
+  // operands assumed): one per 128-column half from the 256-tile kernel, one per 8 columns from the 128-tile kernel, 0 = the
+  // generic kernel would run (no table)
+  if (dtype != CSMOE_BF16 || M <= 0 || N <= 0 || Kd <= 0 || !gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, nullptr, nullptr)) return 0;
+  return use_v2_rowspace(M, N, Kd) ? (N + 127) / 128 : N / 8;
 }
 
 int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, int64_t ldb, const void* bias, int M, int N,

@@ -183,11 +183,23 @@ __global__ void __launch_bounds__(256, 2) gg_fast_kernel(FastArgs p) {
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       const int64_t o = (int64_t)(row0 + r) * p.ldc + ncol;
       bf16x8 o0;
-      if (p.epilogue == CSMOE_EPI_ACTGRAD) {
+      if (p.epilogue == CSMOE_EPI_ACTGRAD || p.epilogue == CSMOE_EPI_ACTGRAD_ROWSCALE) {
         const bf16x8 h8 = *(const bf16x8*)((const bf16*)p.aux + o);
         float h[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { h[j] = (float)h8[j]; v[j] = (float)(bf16)v[j]; }
+        if (p.epilogue == CSMOE_EPI_ACTGRAD_ROWSCALE) {      // per-row scale (C2 slot) applied to the rounded product
+          float* dot_tab = (float*)(p.bias_ptrs ? p.bias_ptrs[e] : p.single_bias);
+          if (dot_tab) {      // sum over this thread's 8 columns of product * aux -> FP32 table [M][NC / 8] (the small-shape kernel
+            float d = 0.f;    // leaves the row reduction to csmoe_affinity_finish; the 256-tile kernel reduces to 128-column halves)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d = fmaf(v[j], h[j], d);
+            dot_tab[(int64_t)(row0 + r) * (p.NC >> 3) + (ncol >> 3)] = d;
+          }
+          const float sc = ((const float*)p.C2)[row0 + r];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (float)(bf16)(sc * v[j]);
+        }
         act_bwd8(h, p.act);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o0[j] = (bf16)(v[j] * h[j]);

@@ -25,7 +25,7 @@ struct EpiArgs {
 constexpr int EPI_LD = 264;                         // staged row stride in bf16 elements (528 B: 16-byte aligned, 4 banks per row)
 constexpr int EPI_LDS_BYTES = 256 * EPI_LD * 2;     // 135,168 B
 
-enum { EC_PLAIN = 0, EC_BIAS = 1, EC_BIAS_ACT = 2, EC_R32_ACT = 3, EC_ACTGRAD = 4 };
+enum { EC_PLAIN = 0, EC_BIAS = 1, EC_BIAS_ACT = 2, EC_R32_ACT = 3, EC_ACTGRAD = 4, EC_ACTGRAD_RS = 5 };   // _RS: + per-row scale (C2 slot)
 constexpr int ACT_RT = -1;                          // activation chosen at run time (the rarer ones share one instantiation)
 
 template <int ACT>
@@ -48,13 +48,21 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][
   const bool col_ok = ncol < p.NC;
 
   bf16x8 hq[16];
-  if constexpr (CLS == EC_ACTGRAD) {
+  if constexpr (CLS == EC_ACTGRAD || CLS == EC_ACTGRAD_RS) {
     if (col_ok) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = er + 16 * i;
         if (r < rows) hq[i] = *(const bf16x8*)((const bf16*)p.aux + (int64_t)(row0 + r) * p.ldc + ncol);
       }
+    }
+  }
+  float rs[16];                                // EC_ACTGRAD_RS: this thread's 16 row scales, fetched with the pre-activations
+  if constexpr (CLS == EC_ACTGRAD_RS) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = er + 16 * i;
+      rs[i] = r < rows ? ((const float*)p.C2)[row0 + r] : 0.f;
     }
   }
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -95,7 +103,11 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][
   asm volatile("" ::: "memory");
 
   // ---- rows
-  if (!col_ok) return;
+  // EC_ACTGRAD_RS with a dot table (EpiArgs::bias slot, FP32 [rows of the launch][ceil(NC / 128)]): per row and 128-column half,
+  // sum_n product[m,n] * aux[m,n] -- the gradient of the reduction weight as the reference forms it, `grad_x_full @ x`
+  // (cvmm.py:544) -- reduced over the 16 threads of the half by shuffles: every thread stays for them
+  float* const dot_tab = (CLS == EC_ACTGRAD_RS) ? (float*)p.bias : nullptr;
+  if (!col_ok && dot_tab == nullptr) return;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = er + 16 * i;
@@ -104,14 +116,33 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][
       const int64_t o = (int64_t)(row0 + r) * p.ldc + ncol;
       if constexpr (CLS == EC_PLAIN || CLS == EC_BIAS) {
         *(bf16x8*)((bf16*)p.C + o) = o0;
-      } else if constexpr (CLS == EC_ACTGRAD) {
+      } else if constexpr (CLS == EC_ACTGRAD || CLS == EC_ACTGRAD_RS) {
         float h[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (float)hq[i][j];
+        for (int j = 0; j < 8; ++j) h[j] = col_ok ? (float)hq[i][j] : 0.f;
+        if constexpr (CLS == EC_ACTGRAD_RS) {
+          if (dot_tab) {                           // wave-uniform
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d = fmaf(col_ok ? (float)o0[j] : 0.f, h[j], d);
+#pragma unroll
+            for (int sh = 8; sh > 0; sh >>= 1) d += __shfl_xor(d, sh, 16);
+            const int half = (threadIdx.x & 31) >> 4;             // a half wholly past the last column has no table entry
+            if ((threadIdx.x & 15) == 0 && tc0 + half * 128 < p.NC)
+              dot_tab[(int64_t)(row0 + r) * ((p.NC + 127) >> 7) + (tc0 >> 7) + half] = d;
+          }
+        }
         epi_act_bwd8<ACT>(h, p.act);
         bf16x8 o1;
+        if constexpr (CLS == EC_ACTGRAD_RS) {      // the reduction weight multiplies the ROUNDED product (cvmm.py:527-543)
+          const float sc = rs[i];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o1[j] = (bf16)((float)o0[j] * h[j]);
+          for (int j = 0; j < 8; ++j) o1[j] = (bf16)((float)(bf16)(sc * (float)o0[j]) * h[j]);
+          if (!col_ok) continue;                   // stayed for the shuffles only
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o1[j] = (bf16)((float)o0[j] * h[j]);
+        }
         *(bf16x8*)((bf16*)p.C + o) = o1;
       } else {
         float v[8];
@@ -212,6 +243,7 @@ __device__ __forceinline__ void rowspace_epilogue(const EpiArgs& p, const f32x4 
                                                   int tc0, int wm, int wn, int lane) {
   switch (p.epilogue) {
     case CSMOE_EPI_ACTGRAD: epi_by_act<EC_ACTGRAD>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_ACTGRAD_ROWSCALE: epi_by_act<EC_ACTGRAD_RS>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
     case CSMOE_EPI_SOFTPLUS_ROWSUM: epi_softplus<false>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
     case CSMOE_EPI_SOFTPLUS_GRAD: epi_softplus<true>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
     case CSMOE_EPI_ROUND_BIAS32_ACT: epi_by_act<EC_R32_ACT>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;

@@ -116,8 +116,9 @@ __global__ void __launch_bounds__(256) gg_generic_kernel(GGArgs p) {
       if (row >= r_lim) continue;
       int64_t o = (int64_t)(tile_r0 + row) * p.ldc + n;
       float v = acc[r];
-      if (p.epilogue == CSMOE_EPI_ACTGRAD) {
+      if (p.epilogue == CSMOE_EPI_ACTGRAD || p.epilogue == CSMOE_EPI_ACTGRAD_ROWSCALE) {
         float g = DT<T>::rnd(v);
+        if (p.epilogue == CSMOE_EPI_ACTGRAD_ROWSCALE) g = DT<T>::rnd(((const float*)p.C2)[tile_r0 + row] * g);
         float h = DT<T>::ld((const T*)p.aux + o);
         DT<T>::st((T*)p.C + o, g * (p.act == CSMOE_ACT_QUICK_GELU ? quick_gelu_grad_rounded<T>(h) : act_bwd(h, p.act)));
       } else {

@@ -97,6 +97,16 @@ def _grouped_colsum(g: torch.Tensor, offsets: torch.Tensor, E: int, pd) -> torch
     return ops.sum_partials(part, E, P, pd)
 
 
+def _gate_wgrad(dlogits: torch.Tensor, x2: torch.Tensor, w_dtype, small: bool) -> torch.Tensor:
+    """d w_gate = dlogits^T @ x in the dtype the product ran in, THEN cast to the parameter's dtype: with an fp32 master under bf16
+    autocast `F.linear` multiplies a bf16 copy of w_gate, autograd's matmul backward returns a bf16 gradient for that copy and the
+    cast's backward widens it (moe_pretrain_model/layers/moe/moe.py:121 under simple_task.py:295) -- the gate gradient the
+    reference's optimizer sees is bf16-rounded (observed: 3e-3 from an unrounded fp32 product, 1e-4 once rounded the same way)."""
+    op = x2.dtype
+    g = ops.gate_bwd_dw(dlogits, x2, op) if small else _chunked_dense_wgrad(dlogits, x2, op)
+    return g if w_dtype == op else g.to(w_dtype)
+
+
 class GateLogits(torch.autograd.Function):
     """logits = x @ w_gate^T rounded to x.dtype -- `self.gate(x)` (moe_model/model/moe/smoe.py:42) /
     `F.linear(x, self.w_gate)` (moe_pretrain_model/layers/moe/moe.py:121)."""
@@ -120,7 +130,7 @@ class GateLogits(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gate_bwd_dx(dlogits, wg) if small else ops.dense_gemm(dlogits, wg, L.B_KN)         # [T,E] @ [E,D]
         if ctx.needs_input_grad[1]:
-            dw = ops.gate_bwd_dw(dlogits, x2, ctx.w_dtype) if small else _chunked_dense_wgrad(dlogits, x2, ctx.w_dtype)
+            dw = _gate_wgrad(dlogits, x2, ctx.w_dtype, small)
         return dx, dw
 
 
@@ -160,7 +170,7 @@ class LayerNormGate(torch.autograd.Function):
             small = ops.gate_bwd_small_ok(xn.shape[1], wg.shape[0], xn.dtype)
             dxn_gate = ops.gate_bwd_dx(dlogits, wg) if small else ops.dense_gemm(dlogits, wg, L.B_KN)     # [T,E] @ [E,D]
             if ctx.needs_input_grad[4]:
-                dwg = ops.gate_bwd_dw(dlogits, xn, wd) if small else _chunked_dense_wgrad(dlogits, xn, wd)
+                dwg = _gate_wgrad(dlogits, xn, wd, small)
         a, b2 = dxn, dxn_gate
         if a is None:
             a, b2 = dxn_gate, None
@@ -239,7 +249,7 @@ class GateSelect(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gate_bwd_dx(ds, wg) if small else ops.dense_gemm(ds, wg, L.B_KN)                     # [T,E] @ [E,D]
         if ctx.needs_input_grad[1]:
-            dwg = ops.gate_bwd_dw(ds, x2, ctx.w_dtype) if small else _chunked_dense_wgrad(ds, x2, ctx.w_dtype)
+            dwg = _gate_wgrad(ds, x2, ctx.w_dtype, small)
         return dx, dwg, None, None, None, None
 
 
@@ -286,6 +296,8 @@ class ExpertTable:
     b2_ptrs: Optional[torch.Tensor] = None
     param_dtype: torch.dtype = torch.float32   # dtype of the gradients handed back
     epi1: int = L.EPI_BIAS_ACT                 # epilogue of the first GEMM (EPI_ROUND_BIAS32_ACT: fp32 b1 table, pretrain autocast)
+    scale_after_gemm: bool = False             # backward of the weighted second GEMM multiplies by the weight AFTER the product is
+                                               # rounded (the pretrain stack's cvmm with reduction weights, cvmm.py:527-543)
 
 
 # Operand-dtype copies of fp32 master weights kept across calls while the parameter is unchanged (same storage, same autograd
@@ -369,6 +381,7 @@ def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residua
 
 
 _WGRAD_SPLIT = os.environ.get("CSMOE_WGRAD_SPLIT", "1") != "0"       # A/B switch
+_SCALE_AFTER_ON = os.environ.get("CSMOE_SCALE_AFTER_GEMM", "1") != "0"   # A/B switch: 0 = dH from dy = round(w * dout) in every stack
 
 
 def _grouped_wgrad(a: torch.Tensor, b: torch.Tensor, bins, E: int, pd) -> torch.Tensor:
@@ -400,14 +413,34 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
     T = dout.shape[0]
     dev = dout.device
     E = tab.E
-    dy, dw = ops.combine_bwd(dout.contiguous(), y if need_dw else None, bins, w, want_dw=need_dw, act_dtype=hact.dtype)
+    ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
+    scale_after = tab.scale_after_gemm and _SCALE_AFTER_ON
+    # gradient of the reduction weights as the reference's weighted cvmm forms it, <unscaled rounded product, activated input>
+    # (cvmm.py:544), out of the dH launch's epilogue -- when its aux operand IS the activated input (ReLU experts keep nothing else)
+    dot_cols = 0
+    if scale_after and need_dw and hpre is None:
+        dot_cols = ops.rowdot_cols(bins.n, tab.F, tab.Dout, tab.Dout, ld2, tab.F, hact.dtype)
+    dy, dw = ops.combine_bwd(dout.contiguous(), y if (need_dw and not dot_cols) else None, bins, w, want_dw=need_dw and not dot_cols,
+                             act_dtype=hact.dtype)
     if dy_extra is not None:                # gradient of the per-slot outputs (MoEFFNModulesSlots), already in binned order
         dy = dy + dy_extra
-    ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
     ld1 = tab.D if tab.layout == L.B_NK else tab.F
     # dH = dY @ W2 (+ activation backward in the epilogue)
-    dh = ops.grouped_gemm(dy, tab.w2_ptrs, _flip(tab.layout), ld2, tab.F, bins.offsets, E, epilogue=L.EPI_ACTGRAD,
-                          act=tab.act, aux=hpre if hpre is not None else hact)
+    if scale_after:
+        # the reference's order for the weighted cvmm: the UNSCALED upstream rows go through the product, the bf16 result is
+        # multiplied by the (bf16) reduction weight and rounded again, then the activation gradient (cvmm.py:527-543 + autograd
+        # of `relu`): a gather of dout rows and a per-row scale in the epilogue instead of dy = round(w * dout) as the operand
+        dyu = ops.dispatch_tokens(dout.contiguous().to(hact.dtype), bins)
+        w_rows = w.reshape(-1)[bins.perm.long()].float().contiguous()
+        dot = torch.empty(bins.n, dot_cols, dtype=torch.float32, device=dev) if dot_cols else None
+        dh = ops.grouped_gemm(dyu, tab.w2_ptrs, _flip(tab.layout), ld2, tab.F, bins.offsets, E, epilogue=L.EPI_ACTGRAD_ROWSCALE,
+                              act=tab.act, aux=hpre if hpre is not None else hact, row_scale=w_rows, row_dot=dot)
+        del dyu
+        if dot is not None:
+            dw = ops.finish_row_dot(dot)[bins.slot_of.long()].view(T, bins.K)
+    else:
+        dh = ops.grouped_gemm(dy, tab.w2_ptrs, _flip(tab.layout), ld2, tab.F, bins.offsets, E, epilogue=L.EPI_ACTGRAD,
+                              act=tab.act, aux=hpre if hpre is not None else hact)
     grads = None
     if need_params:
         pd = tab.param_dtype
@@ -548,6 +581,11 @@ class MoEFFNPacked(torch.autograd.Function):
         the residual's dtype -- the block around the layer (pretrain/block.py); its gradient is the upstream gradient itself."""
         x2 = x2.contiguous()
         op = x2.dtype
+        if op == torch.bfloat16:
+            # `reduction_weight.type_as(res) @ res` (cvmm.py:483, :499): the K weights ENTER the products as bf16 values, but the cast
+            # sits inside the reference's autograd function -- the gradient it returns for the fp32 weights is not rounded.  (Casting
+            # outside, `w.to(bf16).float()`, makes autograd round d w to bf16 on the way back: 1.6e-3 off, tools/grad_stage_probe.py.)
+            w = w.to(op).float()
         E, D, F = keys.shape
         Dout = values.shape[2]
         dev = x2.device
@@ -608,7 +646,7 @@ class MoEFFNPacked(torch.autograd.Function):
             ob = o_bias.contiguous() if o_bias.dtype == op else o_bias.to(op)
         tab = ExpertTable(E=E, D=D, F=F, Dout=Dout, layout=L.B_KN, act=act,
                           w1_ptrs=ops.ptr_table(k_op, E, D * F * es), w2_ptrs=ops.ptr_table(v_op, E, F * Dout * es),
-                          b1_ptrs=b1, b2_ptrs=None, param_dtype=keys.dtype, epi1=epi1)
+                          b1_ptrs=b1, b2_ptrs=None, param_dtype=keys.dtype, epi1=epi1, scale_after_gemm=combine_mode == L.COMBINE_DOT)
         out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, ob, residual=None if residual is None else residual.contiguous(),
                                   before_gemm2=side, masters=masters)
         ctx.has_residual = residual is not None
@@ -897,6 +935,7 @@ class MoEFFNPackedFP8(torch.autograd.Function):
         x2 = x2.contiguous()
         if x2.dtype != torch.bfloat16:
             raise ValueError("competesmoe_amd: the fp8 expert path takes bf16 activations (run under bf16 autocast)")
+        w = w.to(torch.bfloat16).float()          # the K weights enter as bf16 values (as in MoEFFNPacked); d w comes back unrounded
         E, D, F = keys.shape
         T = x2.shape[0]
         bins = ops.bin_tokens(idx, E)

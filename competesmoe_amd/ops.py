@@ -464,16 +464,38 @@ def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: to
 # ------------------------------------------------------------------------------------------------ grouped GEMMs
 def grouped_gemm(A: torch.Tensor, b_ptrs: torch.Tensor, b_layout: int, ldb: int, N: int, offsets: torch.Tensor, E: int,
                  bias_ptrs: Optional[torch.Tensor] = None, epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE,
-                 aux: Optional[torch.Tensor] = None, want_c2: bool = False, force_generic: bool = False, want_c: bool = True):
-    """`want_c=False` (with want_c2 and EPI_BIAS_ACT): only the activated output is written and (None, C2) returned."""
+                 aux: Optional[torch.Tensor] = None, want_c2: bool = False, force_generic: bool = False, want_c: bool = True,
+                 row_scale: Optional[torch.Tensor] = None, row_dot: Optional[torch.Tensor] = None):
+    """`want_c=False` (with want_c2 and EPI_BIAS_ACT): only the activated output is written and (None, C2) returned.
+    `row_scale` (fp32 [M], with EPI_ACTGRAD_ROWSCALE): multiplies the rounded product row by row before the activation gradient;
+    `row_dot` (fp32 [M, rowdot_cols(...)]): receives the partial sums of product * aux (see rowdot_cols / finish_row_dot)."""
     M, Kd = A.shape
     Cm = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c else None
     C2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c2 else None
+    if epilogue == L.EPI_ACTGRAD_ROWSCALE:
+        if row_scale is None or row_scale.dtype != torch.float32 or row_scale.numel() != M or not row_scale.is_contiguous():
+            raise ValueError("csmoe: EPI_ACTGRAD_ROWSCALE needs a contiguous fp32 row_scale [M]")
+        C2 = row_scale                      # the interface passes the scales in the C2 slot
+        if row_dot is not None:
+            bias_ptrs = ptr_table(row_dot, E, 0)        # the interface passes the table in the bias slot (every expert the same)
     with _timed("grouped_gemm_" + ("nt" if b_layout == L.B_NK else "nn"), 2.0 * M * N * Kd):
         L.check(lib.csmoe_grouped_gemm(A.data_ptr(), A.stride(0), b_ptrs.data_ptr(), b_layout, ldb, _ptr(bias_ptrs),
                                        offsets.data_ptr(), E, M, N, Kd, _ptr(Cm), _ptr(C2), _ptr(aux), N, epilogue, act,
                                        _dt(A), int(force_generic), _stream()), "grouped_gemm")
     return (Cm, C2) if want_c2 else Cm
+
+
+def rowdot_cols(M: int, N: int, Kd: int, lda: int, ldb: int, ldc: int, dtype) -> int:
+    """Partial sums per row the EPI_ACTGRAD_ROWSCALE launch of this shape writes into a dot table (0: it would not write one)."""
+    return int(lib.csmoe_grouped_gemm_rowdot_cols(M, N, Kd, lda, ldb, ldc, L.BF16 if dtype == torch.bfloat16 else L.F32))
+
+
+def finish_row_dot(table: torch.Tensor) -> torch.Tensor:
+    """Row sums of a dot table, columns in ascending order (csmoe_affinity_finish with D = 1): fp32 [M]."""
+    M, nt = table.shape
+    out = torch.empty(M, dtype=torch.float32, device=table.device)
+    L.check(lib.csmoe_affinity_finish(table.data_ptr(), M, nt, 1, out.data_ptr(), 1, L.F32, _stream()), "affinity_finish")
+    return out
 
 
 def grouped_gemm_f32w(A: torch.Tensor, B32: torch.Tensor, offsets: torch.Tensor, copy: Optional[torch.Tensor] = None,

@@ -176,9 +176,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         # `relu_pass_rate` every log_interval iterations (compute_scores, moe.py:406-414; upstream tests the bound method
         # `self.train`, which is always true, so evaluation logs too)
         stats = {} if (keys is None and self.log_interval is not None and self.iter % self.log_interval == 0) else None
-        wk = weights.reshape(-1, K)
-        if op == torch.bfloat16:      # `reduction_weight.type_as(res) @ res` (cvmm.py:483, :499): the K weights enter as bf16 values
-            wk = wk.to(op)
+        wk = weights.reshape(-1, K)         # fp32; the bf16 rounding of `reduction_weight.type_as(res)` happens inside the function
         if self.fp8_experts:
             if op != torch.bfloat16:
                 raise ValueError("competesmoe_amd: args.fp8_experts needs bf16 activations (bf16 autocast or a bf16 layer)")
@@ -205,8 +203,6 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         x2 = x.reshape(-1, shp[-1]).to(op)
         K = selected_experts.shape[-1]
         wk = weights.reshape(-1, K)
-        if op == torch.bfloat16:
-            wk = wk.to(op)
         out, y_tk = MoEFFNPackedSlots.apply(x2, wk.float().contiguous(), selected_experts.reshape(-1, K).int().contiguous(),
                                             self.keys, self.values, self.bias, None, self.act_code, L.COMBINE_DOT)
         return out.view(*shp[:-1], -1), y_tk.view(*shp[:-1], K, -1)

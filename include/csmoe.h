@@ -79,7 +79,16 @@ enum {
    *                    vector [M] = d affinity[m]: the gradient of that mean with respect to y, from a recomputed y (autograd of
    *                    the same lines). */
   CSMOE_EPI_SOFTPLUS_ROWSUM = 5,
-  CSMOE_EPI_SOFTPLUS_GRAD = 6
+  CSMOE_EPI_SOFTPLUS_GRAD = 6,
+  /* C[m,n] = round(round(scale[m] * round(acc)) * act'(aux[m,n])) with scale an FP32 vector [M] passed in the C2 slot: the
+   * backward of the pretrain stack's weighted cvmm, which multiplies by the reduction weight AFTER the product has been rounded --
+   * `grad_x_full = cvmm(grad_output, ..)` (unscaled, bf16), then `reduction_weight @ grad_x_full`
+   * (moe_pretrain_model/layers/cvmm.py:527-543) -- so A holds the UNSCALED upstream rows.  (csmoe_grouped_gemm)
+   * Optional dot table in the bias slot (every bias_ptrs[e] the SAME FP32 table [M][csmoe_grouped_gemm_rowdot_cols(..)]): receives
+   * partial sums over column groups of round(acc)[m,n] * aux[m,n]; their row sums (csmoe_affinity_finish with D = 1) are the gradient
+   * of the reduction weights as the reference forms it, `grad_x_full @ x` (cvmm.py:544) -- meaningful when aux is the activated
+   * input of the second product (ReLU experts). */
+  CSMOE_EPI_ACTGRAD_ROWSCALE = 7
 };
 
 int csmoe_version(void);
@@ -176,6 +185,9 @@ int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, in
                        const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd,
                        void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, int dtype,
                        int force_generic, csmoe_stream_t stream);
+
+/* partial sums per row written into the dot table of CSMOE_EPI_ACTGRAD_ROWSCALE for this launch shape; 0: no table (generic kernel) */
+int csmoe_grouped_gemm_rowdot_cols(int M, int N, int Kd, int64_t lda, int64_t ldb, int64_t ldc, int dtype);
 
 /* Dense (single weight matrix) form of the same kernel: C[M,N] = epilogue(A[M,Kd] (x) B), used for the gate projection and
  * the always-on shared expert (moe_model/model/moe/shard_smoe.py:53, deepseekv3.py:44; pretrain deepseekv2.py:154-165). */

@@ -807,3 +807,41 @@ def test_competesmoe_lean_competition_equals_stored_competition(monkeypatch):
         assert abs(a[4][k] - b[4][k]) <= 2e-2 * max(abs(a[4][k]), 1e-3), (k, a[4][k], b[4][k])
     assert (a[2] - b[2]).abs().mean() <= 0.05 * a[2].abs().mean()
     assert (a[3] - b[3]).abs().mean() <= 0.05 * a[3].abs().mean()
+
+
+# ------------------------------------------------------------------------------------------------ weighted-cvmm backward order
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,F,E,K", [(96, 64, 128, 4, 2), (3000, 256, 520, 6, 2), (2500, 128, 136, 3, 1)])
+def test_actgrad_rowscale_epilogue_and_dot_table(T, D, F, E, K):
+    """EPI_ACTGRAD_ROWSCALE: dh = round(round(w * round(g @ W2^T)) * relu'(h)) and the dot table sum_f round(g @ W2^T) * h against the
+    same arithmetic in torch (both bf16 kernels: 128-tile at the small shape, 256-tile at the large ones)."""
+    dev = "cuda"
+    bf = torch.bfloat16
+    gen = torch.Generator(device=dev).manual_seed(T + F)
+    idx = rand_idx(T, K, E, seed=5).to(dev)
+    bins = ops.bin_tokens(idx, E)
+    n = bins.n
+    g = torch.randn(n, D, device=dev, generator=gen).to(bf)                      # unscaled upstream rows, binned order
+    W2 = (torch.randn(E, F, D, device=dev, generator=gen) * D ** -0.5).to(bf)    # K-major [F, D] per expert = cvmm `values`
+    h = torch.relu(torch.randn(n, F, device=dev, generator=gen)).to(bf)
+    wrow = torch.rand(n, device=dev, generator=gen).to(bf).float()
+    cols = ops.rowdot_cols(n, F, D, D, D, F, bf)
+    assert cols == ((F + 127) // 128 if n >= 2048 and F >= 256 and D >= 128 else F // 8)
+    dot = torch.full((n, cols), float("nan"), device=dev)
+    ptrs = ops.ptr_table(W2, E, F * D * 2)
+    dh = ops.grouped_gemm(g, ptrs, L.B_NK, D, F, bins.offsets, E, epilogue=L.EPI_ACTGRAD_ROWSCALE, act=L.ACT_RELU, aux=h,
+                          row_scale=wrow, row_dot=dot)
+    off = bins.offsets.tolist()
+    G = torch.empty(n, F, device=dev, dtype=bf)
+    for e in range(E):
+        G[off[e]:off[e + 1]] = (g[off[e]:off[e + 1]].float() @ W2[e].float().t()).to(bf)
+    ref = ((wrow[:, None] * G.float()).to(bf).float() * (h > 0).float()).to(bf)
+    # the torch product sums in another order than the MFMA chain: G may sit on the other side of a bf16 rounding boundary now and then
+    d = (dh.float() - ref.float()).abs()
+    assert (d > 2.0 ** -6 * ref.float().abs() + 1e-30).float().mean().item() < 1e-4
+    assert (dh != ref).float().mean().item() < 5e-3
+    assert float((dh.float() - ref.float()).norm() / ref.float().norm()) < 1e-3
+    assert not torch.isnan(dot).any()
+    dref = (G.float() * h.float()).sum(-1)
+    got = ops.finish_row_dot(dot)
+    assert torch.allclose(got, dref, rtol=2e-2, atol=2e-2 * dref.abs().mean().item())

@@ -5,9 +5,8 @@ autocast policy the reference trains with (tests/golden/make_golden_pretrain.py,
 Tolerances (observed values: profiles/r02/parity_report.txt): fp32 <= 1e-5 (max err / max|ref|), gradients <= 4e-5 relative L2.
 bf16 autocast: rows routed like the reference <= BF16_OUT relative L2; rows routed differently (exact ties of bf16 logits /
 sigmoids, where torch.topk's choice is unspecified and the kernel takes the lowest index) <= BF16_BAD_ROWS of the fixture;
-gradients <= BF16_GRAD (the HIP backward scales the upstream gradient by the weight BEFORE the dH GEMM, cvmm.py:538-547 scales
-the rounded product after it: one bf16 rounding apart).  Competition steps route on fp32 affinities like the reference, so the
-same bounds hold for them."""
+gradients <= BF16_GRAD (the backward of the weighted cvmm keeps the reference's order, cvmm.py:527-547: see BF16_GRAD below).
+Competition steps route on fp32 affinities like the reference, so the same bounds hold for them."""
 import types
 
 import pytest
@@ -23,7 +22,13 @@ if torch.cuda.is_available():
     from competesmoe_amd.pretrain import get_moe, cvmm, cvmm_prepare_sel2
 
 CASES = ["smoe", "smoe_bias", "competesmoe_router", "competesmoe_comp", "competesmoe_comp_hybrid", "deepseekv2", "deepseekv3"]
-BF16_OUT, BF16_BAD_ROWS, BF16_GRAD = 2e-4, 0.01, 6e-3        # observed maxima: 5.8e-5, 0.0078 (deepseekv3 sigmoid ties), 4.3e-3
+BF16_OUT, BF16_BAD_ROWS = 2e-4, 0.01        # observed maxima: 5.8e-5, 0.0078 (deepseekv3 sigmoid ties)
+# bf16 gradients against the reference's (profiles/r02/parity_report.txt).  With the reference's order in the weighted cvmm's backward
+# (product rounded, THEN the reduction weight; d weight = <unscaled product, activated input>, returned unrounded) and its bf16-rounded
+# gate gradient, dx and d w_gate of `smoe` are the reference's bits and the expert weights 2e-8 / 7e-6; the fp32-bias case keeps a
+# 3e-3 gate gradient (the reference's dot takes the UNROUNDED fp32 scores there, this path keeps bf16 scores)
+BF16_GRAD = 1e-3
+BF16_GRAD_CASE = {"smoe_bias": 6e-3}
 
 
 def build(fx):
@@ -94,6 +99,7 @@ def test_pretrain_layer_matches_golden(case, tag):
                 continue
             assert rel_l2(p.grad, g.to(DEV)) <= 4e-5, (name, rel_l2(p.grad, g.to(DEV)))
     elif routed_same:
+        BF16_GRAD = BF16_GRAD_CASE.get(case, globals()["BF16_GRAD"])
         assert rel_l2(x.grad, fx["x_grad"].to(DEV)) <= BF16_GRAD, rel_l2(x.grad, fx["x_grad"].to(DEV))
         for name, p in layer.named_parameters():
             g = fx["grads"].get(name)
