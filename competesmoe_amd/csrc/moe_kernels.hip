@@ -66,7 +66,12 @@ __global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scor
     else if (mode == CSMOE_SEL_RAW) denom = round_dt(ssum, dtype);
     else denom = ssum + 1e-20f;
     float dot = wave_sum(mydw * myv);
-    dv = mydw / denom - dot / (denom * denom);
+    // d/d(denominator) = -sum_k dw_k v_k / denom^2.  Where the reference casts the K-sum to x.dtype (`.to(x.dtype)`, smoe.py:44) the
+    // denominator is a bf16 TENSOR, and autograd hands a bf16 tensor a bf16 gradient: that term is rounded before it is broadcast
+    // back to the K values (observed: d gate.weight 3.2e-3 off and half its elements different without the rounding).
+    float dden = -dot / (denom * denom);
+    if (round_sum_bf16 && (mode == CSMOE_SEL_SOFTMAX || mode == CSMOE_SEL_TOPK_SIGMOID)) dden = (float)(bf16)dden;
+    dv = mydw / denom + dden;
     if (mode == CSMOE_SEL_SIGMOID) dv *= myv * (1.f - myv);
     if (mode == CSMOE_SEL_TOPK_SIGMOID) dv *= myv * (1.f - myv) / sel_param;
   }
