@@ -2,8 +2,11 @@
 against goldens captured from the reference's RelativeMoeTransformerEncoderLayer (tests/golden/make_golden_pretrain_block.py), and
 the mixed-precision kernels underneath (fp32 residual stream around bf16 activations) against torch.
 
-fp32 <= 1e-5 (max err / max|ref|); bf16 autocast <= 4e-3 relative L2 on the rows whose routing agrees (CPU-autocast goldens, as in
-tests/test_pretrain_modules_gpu.py)."""
+fp32 <= 1e-5 (max err / max|ref|).  bf16 autocast (goldens from the reference's own Triton kernels under the CUDA autocast policy,
+tests/golden/ref_env.py; observed values: tools/block_parity_probe.py): `smoe` / `competesmoe` blocks reproduce the reference's
+OUTPUT BITS and every gradient to 1.4e-7 on router steps; competition steps keep the output bits, gradients of the stream and of
+the LayerNorm 3e-4 / 1.7e-3 (the dense pass's gradients meet in another order); deepseekv3 routes 2 % of the fixture's rows on a
+tie of bf16 sigmoids differently (the kernel takes the lowest index), the others agree to 1.1e-4."""
 import types
 
 import pytest
@@ -72,8 +75,8 @@ def test_pretrain_block_matches_reference(case, tag):
         row_err = (o2 - g2).norm(dim=-1) / (g2.norm(dim=-1) + 1e-12)
         bad = row_err > 5e-2
         routed_same = not bool(bad.any())
-        assert bad.float().mean() <= (0.03 if not comp else 0.12), bad.float().mean()
-        assert rel_l2(o2[~bad], g2[~bad]) <= 6e-3, rel_l2(o2[~bad], g2[~bad])
+        assert bad.float().mean() <= (0.03 if case == "deepseekv3" else 0.0), bad.float().mean()
+        assert rel_l2(o2[~bad], g2[~bad]) <= 5e-4, rel_l2(o2[~bad], g2[~bad])
     for k, v in fx["reg_loss"].items():
         assert abs(float(reg[k]) - float(v)) <= (2e-6 if not bf16 else (2e-4 if not comp else 2e-3)) + 1e-4 * abs(float(v)), k
     loss = (out.float() * dy).sum() + sum(v.float() for v in reg.values())
@@ -88,13 +91,14 @@ def test_pretrain_block_matches_reference(case, tag):
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
                 continue
             assert rel_l2(p.grad, g.to(DEV)) <= 4e-5, (name, rel_l2(p.grad, g.to(DEV)))
-    elif not comp and routed_same:
+    elif routed_same:
         assert x.grad.dtype == torch.float32
-        assert rel_l2(x.grad, fx["mid_grad"].to(DEV)) <= 1e-2
-        assert rel_l2(blk.norm2.weight.grad, fx["norm2_grads"]["weight"].to(DEV)) <= 2e-2
-        assert rel_l2(blk.norm2.bias.grad, fx["norm2_grads"]["bias"].to(DEV)) <= 2e-2
+        gx, gln, gw = (1e-4, 1e-4, 1e-4) if not comp else (2e-3, 6e-3, 3e-4)
+        assert rel_l2(x.grad, fx["mid_grad"].to(DEV)) <= gx
+        assert rel_l2(blk.norm2.weight.grad, fx["norm2_grads"]["weight"].to(DEV)) <= gln
+        assert rel_l2(blk.norm2.bias.grad, fx["norm2_grads"]["bias"].to(DEV)) <= gln
         for name in ("keys", "values", "w_gate"):
-            assert rel_l2(getattr(layer, name).grad, fx["grads"][name].to(DEV)) <= 2e-2, name
+            assert rel_l2(getattr(layer, name).grad, fx["grads"][name].to(DEV)) <= gw, name
 
 
 # ------------------------------------------------------------------------------------------------ mixed-precision kernels
