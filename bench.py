@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--skew", action="store_true", help="add +2.0 to 8 gate rows (Zipf-like load, BASELINE.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=4096)
+    ap.add_argument("--graph", action="store_true", help="time REPLAYS of the step captured as one hipGraph (competesmoe_amd.graphs.GraphedStep): the launch-bound small shapes; the per-kernel table comes from eager steps run before the capture")
     ap.add_argument("--competition", action="store_true", help="time the CompeteSMoE competition step (every expert dense + sparse recompute) instead of the sparse smoe step")
     ap.add_argument("--block", action="store_true", help="time the block around the layer, x + MoE(LayerNorm(x)) (SURVEY.md section 8 f1), with the fused LayerNorm+gate / residual-combine kernels")
     ap.add_argument("--block-unfused", action="store_true", help="same block composed from torch LayerNorm, the plain layer and a torch add (A/B for --block)")
@@ -312,13 +313,39 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    ops.profile_start()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    el = time.perf_counter() - t0
-    prof = ops.profile_stop()
+    if a.graph:
+        assert world == 1 and a.stack == "llava" and blk is None and ln is None and not a.force_ep, "--graph: single-GPU LLaVA-stack layer only"
+        from competesmoe_amd.graphs import GraphedStep
+        ops.profile_start()
+        for _ in range(min(5, a.steps)):
+            step()
+        fence()
+        prof = ops.profile_stop()
+        prof = {k: {**v, "calls": v["calls"] * a.steps / min(5, a.steps)} for k, v in prof.items()}       # per-step counts of the table below
+        x.grad = None
+        for p in layer.parameters():
+            p.grad = None
+
+        def loss_fn(xi):
+            out, aux, _, _ = layer(xi)
+            return (out.float() * dy.float()).sum() + aux.float()
+        gstep = GraphedStep(loss_fn, [x], list(layer.parameters()))
+        for _ in range(a.warmup):
+            gstep(x)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            gstep(x)
+        fence()
+        el = time.perf_counter() - t0
+    else:
+        ops.profile_start()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        prof = ops.profile_stop()
     if world > 1:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -365,7 +392,7 @@ def main():
             "config": {"workload": ((f"BASELINE config 5: pretrain-stack deepseekv2 layer, {a.experts} routed + {a.shared} shared experts, GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 matrix pipe (fp32 master weights quantised directly, bf16 weight gradients): " if a.dtype == "fp8" else "pretrain-stack layer (packed fp32 master weights, ReLU, no bias, bf16 autocast; weights cast to bf16 every step): ") if a.stack == "pretrain" else "") + ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
                                    f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, " + ("ReLU experts without bias, " if a.stack == "pretrain" else "Linear+bias/GELU experts, ") +
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
-                       "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
+                       "graph_replay": bool(a.graph), "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
                        "parallelism": "single GPU" if world == 1 else f"ep{world} (experts sharded, RCCL all-to-all)",
                        **({"ep_chunks": layer.chunks, "ep_chunks_trial_ms": ep_tune} if (world > 1 or a.force_ep) else {})},
             "roofline": roof, "kernels": detail,
