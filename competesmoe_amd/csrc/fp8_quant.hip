@@ -119,14 +119,15 @@ __global__ void __launch_bounds__(256) quant_cols_kernel(const void* const* x_pt
 
 // both orientations in ONE pass over the source (weights: the forward product needs blocks along one dim, the backward product
 // along the other; reading 4-byte masters twice was the larger half of the fp8 step's quantisation time).  One 256-thread
-// workgroup per 32-row x 128-column tile: 16-byte global loads (512 B per row and wave-instruction) into an fp32 LDS tile, then
-// the 128 (row, 32-column block) pairs and the 128 columns (one 32-row block each) are quantised by one thread each straight from
-// LDS -- rows by ds_read_b128 along the row, columns by ds_read_b32 down the column (consecutive lanes = consecutive banks) -- and
-// every output leaves as 16-byte stores.  6 B of HBM traffic per element with fp32 masters (4 read + 2 written).
-// Tried and dropped (gpurun_out r2x): a 128 x 128 tile (128-byte runs of the transposed copy, 16 loads in flight per thread, 66 KiB
-// of LDS = 2 workgroups per CU): 5.49 ms against 4.50 ms per call -- the load / quantise phases of a workgroup do not overlap, so the
-// eight resident workgroups of the small tile are what keeps HBM busy.
-constexpr int QB_R = 32, QB_C = 128, QB_LD = QB_C + 4;       // +4 floats: rows 16 B apart in bank space (b128 row reads)
+// workgroup per 64-row x 128-column tile: 16-byte global loads (512 B per row and wave-instruction, 8 in flight per thread) into an
+// fp32 LDS tile (33 KiB: four workgroups per CU), then the 256 (row, 32-column block) units and the 256 (column, 32-row block) units
+// are quantised one each per thread straight from LDS -- rows by ds_read_b128 along the row, columns by ds_read_b32 down the
+// column (consecutive lanes = consecutive banks) -- and every output leaves as 16-byte stores; two threads complete a 64-byte run
+// of a transposed row.  6 B of HBM traffic per element with fp32 masters (4 read + 2 written).
+// Tile height, same box (gpurun_out r2x / r3n): 32 rows (lone 32-byte pieces of the transposed rows, 8 workgroups per CU) 4.50 ms per
+// call = 3.9 TB/s; 64 rows 4.18 ms = 4.2 TB/s; 128 rows (66 KiB of LDS, 2 workgroups per CU: too few to keep HBM busy while a
+// workgroup's load and quantise phases do not overlap) 5.49 ms.
+constexpr int QB_R = 64, QB_C = 128, QB_LD = QB_C + 4;       // +4 floats: rows 16 B apart in bank space (b128 row reads)
 
 template <typename T>
 __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_ptrs, const T* x_single, int64_t ldx, int R, int C,
@@ -140,17 +141,17 @@ __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_pt
   uint8_t* qte = qt + (int64_t)e * q_mat;       // [C, R]
   uint8_t* ste = st + (int64_t)e * st_mat;      // [C, R/32]
   const int t = threadIdx.x;
-  const int rb_n = R / QB_R, cb_n = (C + QB_C - 1) / QB_C, nbc = C >> 5;
-  const int64_t tiles = (int64_t)rb_n * cb_n;
+  const int rt_n = (R + QB_R - 1) / QB_R, cb_n = (C + QB_C - 1) / QB_C, nbc = C >> 5, nbr = R >> 5;
+  const int64_t tiles = (int64_t)rt_n * cb_n;
   for (int64_t ti = blockIdx.x; ti < tiles; ti += gridDim.x) {
-    const int rb = (int)(ti / cb_n), cb = (int)(ti - (int64_t)rb * cb_n);
-    const int r0 = rb * QB_R, c0 = cb * QB_C;
-    // ---- load: thread -> (row t / 32 + 8 i, 4 columns (t % 32) * 4)
+    const int rt = (int)(ti / cb_n), cb = (int)(ti - (int64_t)rt * cb_n);
+    const int r0 = rt * QB_R, c0 = cb * QB_C;
+    // ---- load: thread -> (row t / 32 + 8 i, 4 columns (t % 32) * 4), 8 rows per thread
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int r = (t >> 5) + 8 * i, c = (t & 31) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (c0 + c < C) {
+      if (c0 + c < C && r0 + r < R) {
         const T* src = x + (int64_t)(r0 + r) * ldx + c0 + c;
         if constexpr (std::is_same<T, float>::value) {
           v = *(const f32x4*)src;
@@ -162,10 +163,10 @@ __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_pt
       *(f32x4*)(tile + r * QB_LD + c) = v;
     }
     __syncthreads();
-    if (t < 128) {
-      // ---- row-major output: pair (row t / 4, column block t % 4)
+    {
+      // ---- row-major output: unit (row t / 4, column block t % 4)
       const int r = t >> 2, bk = t & 3;
-      if (c0 + bk * 32 < C) {
+      if (c0 + bk * 32 < C && r0 + r < R) {
         float v[32];
         float amax = 0.f;
 #pragma unroll
@@ -187,14 +188,15 @@ __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_pt
         *(u32x4*)(dst + 16) = o1;
         se[(int64_t)(r0 + r) * nbc + (c0 >> 5) + bk] = (uint8_t)sb;
       }
-    } else {
-      // ---- transposed output: column t - 128, its 32 rows
-      const int c = t - 128;
-      if (c0 + c < C) {
+    }
+    {
+      // ---- transposed output: column t % 128, row block t / 128 (two threads complete a 64-byte run of the column)
+      const int c = t & 127, rbk = t >> 7;
+      if (c0 + c < C && r0 + rbk * 32 < R) {
         float v[32];
         float amax = 0.f;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { v[i] = tile[i * QB_LD + c]; amax = fmaxf(amax, fabsf(v[i])); }
+        for (int i = 0; i < 32; ++i) { v[i] = tile[(rbk * 32 + i) * QB_LD + c]; amax = fmaxf(amax, fabsf(v[i])); }
         const int sb = e8m0_of_amax(amax);
         const float inv = inv_scale_of(sb);
         u32x4 o0, o1;
@@ -203,10 +205,10 @@ __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_pt
           o0[j] = pack4_e4m3(v[4 * j] * inv, v[4 * j + 1] * inv, v[4 * j + 2] * inv, v[4 * j + 3] * inv);
           o1[j] = pack4_e4m3(v[16 + 4 * j] * inv, v[17 + 4 * j] * inv, v[18 + 4 * j] * inv, v[19 + 4 * j] * inv);
         }
-        uint8_t* dst = qte + (int64_t)(c0 + c) * R + r0;
+        uint8_t* dst = qte + (int64_t)(c0 + c) * R + r0 + rbk * 32;
         *(u32x4*)dst = o0;
         *(u32x4*)(dst + 16) = o1;
-        ste[(int64_t)(c0 + c) * rb_n + rb] = (uint8_t)sb;
+        ste[(int64_t)(c0 + c) * nbr + (r0 >> 5) + rbk] = (uint8_t)sb;
       }
     }
     __syncthreads();
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_pt
 int k_quantize_mxfp8_both(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, void* q,
                           void* s, void* qt, void* st, hipStream_t stream) {
   if (E <= 0 || R <= 0 || C <= 0) return CSMOE_OK;
-  const int64_t tiles = (int64_t)(R / QB_R) * ((C + QB_C - 1) / QB_C);
+  const int64_t tiles = (int64_t)((R + QB_R - 1) / QB_R) * ((C + QB_C - 1) / QB_C);
   dim3 grid((unsigned)std::min<int64_t>(tiles, 16384), (unsigned)E), block(256);
   const int64_t q_mat = (int64_t)R * C, s_mat = (int64_t)R * (C / 32), st_mat = (int64_t)C * (R / 32);
   if (in_dtype == CSMOE_BF16)
