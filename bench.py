@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--stack", default="llava", choices=["llava", "pretrain"], help="pretrain: the LM-pretrain stack's `smoe` layer (packed fp32 master weights keys/values, ReLU, no bias, bf16 autocast: the cvmm path) instead of the LLaVA-stack layer")
     ap.add_argument("--ep-chunks", type=int, default=0, help="expert-parallel runs: groups of local experts whose all-to-all overlaps the grouped GEMMs (competesmoe_amd.ep); 0 = pick the fastest of 1 / 2 / 4 in a short untimed trial before the warmup (1 with a single rank)")
     ap.add_argument("--ep-trial", action="store_true", help="run the overlap-depth trial even with a single rank (exercises the N>1 control flow on one GPU)")
+    ap.add_argument("--stub", action="store_true", help="launcher test: CPU stand-in step over gloo, no GPU (tests/test_bench_launcher.py)")
     ap.add_argument("--force-ep", action="store_true", help="use the expert-parallel layer even with one rank (smoke-tests the N>1 code path)")
     return ap.parse_args()
 
@@ -144,11 +145,33 @@ def make_pretrain_layer(a, dev):
     return layer
 
 
+def host_cores():
+    """(physical cores, logical CPUs, model name) from /proc/cpuinfo: distinct (physical id, core id) pairs."""
+    pairs, logical, model, phys_id = set(), 0, "unknown", "0"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("processor"):
+                    logical += 1
+                elif ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    phys_id = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    pairs.add((phys_id, ln.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    logical = logical or (os.cpu_count() or 1)
+    return (len(pairs) or logical), logical, model
+
+
 def cpu_baseline(a):
     """CPU oracle (port of the reference layer) on a bounded sample: same D/F/E/K, fp32, `cpu_tokens` tokens."""
     from oracle import moe_oracle as O
     D, F, E, K, T = a.d_model, a.d_ff, a.experts, a.topk, a.cpu_tokens
-    cores = torch.get_num_threads()
+    phys, logical, cpu_model = host_cores()
+    cores = max(1, min(phys, len(os.sched_getaffinity(0))))     # one thread per PHYSICAL core this process may run on (BASELINE.md section 4)
+    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(1)
     w1 = torch.empty(F, D).normal_(0, 0.02, generator=g)
     w2 = torch.empty(D, F).normal_(0, 0.02, generator=g)
@@ -170,40 +193,106 @@ def cpu_baseline(a):
     k1 = (torch.randn(E1, D1, F1, generator=g1) * D1 ** -0.5).requires_grad_(True)
     v1 = (torch.randn(E1, F1, D1, generator=g1) * (E1 * F1) ** -0.5).requires_grad_(True)
     wg1 = (torch.randn(E1, D1, generator=g1) * D1 ** -0.5).requires_grad_(True)
-    best = None
-    for _ in range(3):
+    # a 1024-token problem: 8 threads (the reference's own CPU-runnable case is a workstation-sized one; on 64+ threads the
+    # per-op fork/join of torch's pool costs more than the 0.2 GFLOP of work and the timing swung 12x between boxes in round 2),
+    # two untimed passes after the 23-GB job above, then the MEDIAN of 7
+    c1 = min(8, cores)
+    torch.set_num_threads(c1)
+    times = []
+    for it in range(9):
+        for t_ in (x1, k1, v1, wg1):
+            t_.grad = None
         t1 = time.perf_counter()
         lg = O.gate_logits(x1, wg1)
         w1_, i1, _ = O.router_topk(lg, K1, x1.dtype)
         o1 = O.pretrain_ffn(x1, i1, w1_, k1, v1, "relu", torch.float32)
         (o1.sum() + O.entropy_balance(lg) * 0.01).backward()
-        d1 = time.perf_counter() - t1
-        best = d1 if best is None else min(best, d1)
-    cpu_model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as fh:
-            for ln in fh:
-                if ln.startswith("model name"):
-                    cpu_model = ln.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
+        if it >= 2:
+            times.append(time.perf_counter() - t1)
+    torch.set_num_threads(cores)
+    med = sorted(times)[len(times) // 2]
     return {"value": T / dt_s, "unit": "tokens/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
-            "config1_tokens_per_s": round(T1 / best, 1),
-            "sample": f"CPU oracle (fp32 port of the reference SMoE layer) on {cores} threads of {cpu_model}: one fwd+bwd of {T} tokens, "
+            "physical_cores": phys, "logical_cpus": logical,
+            "config1_tokens_per_s": round(T1 / med, 1), "config1_threads": c1,
+            "sample": f"CPU oracle (fp32 port of the reference SMoE layer) on {cores} threads = one per physical core of {cpu_model} "
+                      f"({phys} physical cores, {logical} logical CPUs): one fwd+bwd of {T} tokens, "
                       f"D={D} F={F} E={E} K={K}, {dt_s:.1f} s; BASELINE config 1 in full (pretrain-style layer D=256 F=128 E=8 K=2, "
-                      f"1024 tokens): {best * 1e3:.1f} ms per fwd+bwd"}
+                      f"1024 tokens) on {c1} threads: median of 7 after 2 warm passes {med * 1e3:.1f} ms per fwd+bwd "
+                      f"(min {min(times) * 1e3:.1f}, max {max(times) * 1e3:.1f})"}
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python3 bench.py --gpus N` typed as is (no launcher around it): start N fresh ranks -- `python -m torch.distributed.run`,
+    one process per GPU, rendezvous on 127.0.0.1 -- as a CHILD of this process, which has not touched the GPU (importing torch does
+    not initialise HIP), relay their output (rank 0 prints the ONE JSON line) and return the children's exit status.  Never an
+    exec: a process that has initialised the GPU must not be replaced, and this one stays alive to pass the status on.
+    (The reference's launch for comparison: moe_pretrain_model/train.sh:34-39.)"""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what this pool's driver supports (RCCL over xGMI)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_main(a, rank, world):
+    """--stub: the N>1 control flow (rendezvous, barrier-bracketed timed region, max over ranks, one JSON line from rank 0) over
+    gloo with a CPU stand-in for the step -- what tests/test_bench_launcher.py runs at world 2 in a container without GPUs.  Not a
+    measurement: `data` says so."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = torch.randn(64, 64)
+
+    def step():
+        return (w @ w).sum()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    el = float(tt)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(a.tokens * world * a.steps / el, 1), "unit": "tokens/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "stub step on CPU over gloo (launcher test)",
+                          "config": {"workload": "launcher stub", "ranks": world, "comm_world_size": dist.get_world_size() if world > 1 else 1}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            print(f"bench.py: --gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} ...`", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} ranks", file=sys.stderr)
+        sys.exit(2)
+    if a.stub:
+        return stub_main(a, rank, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if a.dtype == "fp8":
@@ -394,7 +483,8 @@ def main():
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
                        "graph_replay": bool(a.graph), "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
                        "parallelism": "single GPU" if world == 1 else f"ep{world} (experts sharded, RCCL all-to-all)",
-                       **({"ep_chunks": layer.chunks, "ep_chunks_trial_ms": ep_tune} if (world > 1 or a.force_ep) else {})},
+                       **({"ep_chunks": layer.chunks, "ep_chunks_trial_ms": ep_tune, "comm_world_size": dist.get_world_size(),
+                           "comm_backend": "nccl (RCCL)"} if (world > 1 or a.force_ep) else {})},
             "roofline": roof, "kernels": detail,
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }

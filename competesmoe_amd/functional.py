@@ -438,6 +438,12 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
         del dyu
         if dot is not None:
             dw = ops.finish_row_dot(dot)[bins.slot_of.long()].view(T, bins.K)
+        if dy_extra is not None:
+            # the per-slot outputs (MoEFFNPackedSlots: the diversity loss's operands) are UNWEIGHTED rows of the second product, so
+            # their gradient goes through W2^T and the activation gradient as it stands -- the reference backpropagates the
+            # diversity loss through relu(x @ keys[e]) too (pretrain competesmoe.py:403-410) -- and carries no d w
+            dh = dh + ops.grouped_gemm(dy_extra.contiguous(), tab.w2_ptrs, _flip(tab.layout), ld2, tab.F, bins.offsets, E,
+                                       epilogue=L.EPI_ACTGRAD, act=tab.act, aux=hpre if hpre is not None else hact)
     else:
         dh = ops.grouped_gemm(dy, tab.w2_ptrs, _flip(tab.layout), ld2, tab.F, bins.offsets, E, epilogue=L.EPI_ACTGRAD,
                               act=tab.act, aux=hpre if hpre is not None else hact)

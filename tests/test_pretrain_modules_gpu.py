@@ -288,3 +288,31 @@ def test_pretrain_competition_without_stored_outputs_matches_golden(case, monkey
     monkeypatch.setenv("CSMOE_COMPETITION_LEAN", "1")
     test_pretrain_layer_matches_golden(case, "bf16")
     assert calls, "the lean competition pass was not taken"
+
+
+def test_pretrain_lean_competition_backpropagates_the_diversity_loss_through_the_first_product(monkeypatch):
+    """with CSMOE_COMPETITION_LEAN=1 the gradient of the per-slot expert outputs (the diversity loss's operands,
+    pretrain competesmoe.py:403-410) must reach `keys` and x through relu(x @ keys[e]), as the stored form's dense pass sends it.
+    The loss here is the diversity term alone (every other coefficient zero, the output unused), so a dropped path shows as a
+    zero / wrong gradient instead of hiding under the output term.  Bound: the two forms differ by where bf16 roundings fall
+    (stored: the dense dy carries affinity + diversity gradients in one product; lean: two products summed)."""
+    fx = load("pretrain_competesmoe_comp_bf16")
+    grads = {}
+    for lean in ("0", "1"):
+        monkeypatch.setenv("CSMOE_COMPETITION_LEAN", lean)
+        layer, kw = build(fx)
+        layer.args.balance_loss_coef_comp = 2.0
+        layer.args.router_loss_coef = 0.0
+        layer.args.balance_affinity = False
+        x = fx["x"].to(DEV).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = layer(x, **kw)
+            reg = layer.get_reg_loss()
+        name = [k for k in reg if k.endswith("_comp_diver_loss")]
+        assert len(name) == 1
+        (reg[name[0]].float() + 0.0 * out.float().sum()).backward()
+        grads[lean] = {"x": x.grad.clone(), "keys": layer.keys.grad.clone(), "values": layer.values.grad.clone()}
+    for k in ("x", "keys", "values"):
+        a, b = grads["1"][k], grads["0"][k]
+        assert float(b.abs().max()) > 0, k
+        assert rel_l2(a, b) <= 5e-3, (k, rel_l2(a, b))
