@@ -437,20 +437,21 @@ def pretrain_diversity_loss(topk_out: torch.Tensor, op_dtype=None) -> torch.Tens
     return sim.mean()
 
 
-def pretrain_deepseek_forward(x, w_gate, keys, values, keys_shared, values_shared, k, mode: str, op_dtype, x_dtype):
+def pretrain_deepseek_forward(x, w_gate, keys, values, keys_shared, values_shared, k, mode: str, op_dtype, x_dtype, forced_idx=None):
     """DeepSeekV2.forward (moe_pretrain_model/layers/moe/deepseekv2.py:135-181: top-k of the logits, softmax over the K)
     and DeepSeekV3.forward (deepseekv3.py:142-190: top-k of sigmoid(logits), w / (sum + 1e-20)), both plus the always-on shared
-    expert (a 1-expert cvmm with an all-zero selection and unit weight = a dense FFN).  Returns (out, gate_logits)."""
+    expert (a 1-expert cvmm with an all-zero selection and unit weight = a dense FFN).  Returns (out, gate_logits).
+    `forced_idx`: evaluate with given (tie-broken) indices -- the reference's own, or the kernel's -- instead of the lowest-index rule."""
     B, N, D = x.shape
     xx = x.to(op_dtype)
     lg = F.linear(xx, w_gate.to(op_dtype))
     # bf16 logits = the run under CUDA autocast: softmax and sum are fp32-policy ops there, sigmoid is not
     if mode == "deepseekv2":
-        idx = topk_lowest_index(lg.detach().float(), k)[1]
+        idx = topk_lowest_index(lg.detach().float(), k)[1] if forced_idx is None else forced_idx
         w = F.softmax(torch.gather(lg, -1, idx).float(), dim=-1).to(x_dtype)
     else:
         sg = torch.sigmoid(lg)
-        idx = topk_lowest_index(sg.detach().float(), k)[1]
+        idx = topk_lowest_index(sg.detach().float(), k)[1] if forced_idx is None else forced_idx
         w = torch.gather(sg, -1, idx)
         w = w / (w.float().sum(dim=-1, keepdim=True) + 1e-20)
     out = pretrain_ffn(x, idx, w, keys, values, "relu", op_dtype)

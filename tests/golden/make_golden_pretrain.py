@@ -88,9 +88,24 @@ def run_case(name, moe_name, bf16, *, B=2, N=64, D=64, E=8, F_=32, K=2, competit
 
         xg = x.clone().requires_grad_(True)
         layer.regularization_present = True
-        with amp(bf16, upcasts):
-            out = layer(xg, **kw)
-            reg = layer.get_reg_loss()
+        # what the reference's forward selected: the index result of every torch.topk call it makes (gate top-k first; on a
+        # competition step the affinity top-k second) -- torch.topk's choice among exactly tied bf16 scores is unspecified, so the
+        # fixture records it (tests force the oracle to these rows to pin its gradients where a tie exists)
+        topk_idx = []
+        orig_topk = torch.topk
+
+        def spy_topk(*a_, **k_):
+            r = orig_topk(*a_, **k_)
+            topk_idx.append(r[1].detach().clone())
+            return r
+        torch.topk = spy_topk
+        try:
+            with amp(bf16, upcasts):
+                out = layer(xg, **kw)
+                reg = layer.get_reg_loss()
+        finally:
+            torch.topk = orig_topk
+        fx["selected_experts"] = topk_idx[0]
         fx["output"] = out.detach().clone()
         fx["reg_loss"] = {k: v.detach().clone() for k, v in reg.items()}
         loss = (out.float() * dy).sum() + sum(v.float() for v in reg.values())

@@ -185,3 +185,109 @@ def test_config4_siglip_layer_shape_router_and_competition_steps(monkeypatch):
     assert (dx3 - dx2).norm() / dx2.norm() <= 5e-2 and (g3 - g2).norm() / g2.norm() <= 5e-2
     o3b, dx3b, g3b, _ = run(True, "1")
     assert torch.equal(o3, o3b) and torch.equal(dx3, dx3b) and torch.equal(g3, g3b)
+
+
+def test_gate_select_full_size_equals_the_two_launch_router(routed):
+    """The one-pass router the headline step uses (csmoe_gate_select) at T = 32 768, E = 64 against the reference's two methods as
+    two launches (gate GEMM + router_select, the `routed` fixture): logits, fp32 softmax, indices and weights bit for bit, and the
+    block histogram it hands to the binning gives the same bins (VERDICT r2 weak #5: largest tested T was 1 000)."""
+    x, logits, sm, idx, w, bins = routed
+    g = torch.Generator(device=DEV).manual_seed(0)
+    torch.randn(T, D, device=DEV, generator=g)                                  # the fixture's x draw
+    wg = (torch.randn(E, D, device=DEV, generator=g) * 0.02).bfloat16()
+    assert ops.gate_select_ok(x, wg, K)
+    lg1, sm1, idx1, w1 = ops.gate_select(x, wg, K, L.SEL_SOFTMAX, True)
+    assert torch.equal(lg1, logits) and torch.equal(sm1, sm) and torch.equal(idx1, idx) and torch.equal(w1, w)
+    b1 = ops.bin_tokens(idx1, E)                                                # picks up the launch's block histogram
+    for a, b in ((b1.counts, bins.counts), (b1.offsets, bins.offsets), (b1.perm, bins.perm), (b1.slot_of, bins.slot_of)):
+        assert torch.equal(a, b)
+    lg2, sm2, idx2, w2 = ops.gate_select(x, wg, K, L.SEL_SOFTMAX, True)        # run-to-run: same bits
+    assert torch.equal(lg2, lg1) and torch.equal(idx2, idx1) and torch.equal(w2, w1)
+
+
+def test_nn_layout_and_activation_gradient_epilogue_full_size(routed):
+    """The backward's row-space launches at the headline shape: dH = act'(h_pre) * (dY @ W2) (K-major weights = the NN product,
+    EPI_ACTGRAD epilogue, K = 4096 -> N = 11008) and dXs = dH @ W1 (NN, plain, K = 11008 -> N = 4096), sampled against fp64 dot
+    products; linearity in the upstream rows; rows of an empty expert range untouched by neighbours (VERDICT r2 weak #5)."""
+    x, logits, sm, idx, w, bins = routed
+    g = torch.Generator(device=DEV).manual_seed(7)
+    n = bins.n
+    W2 = (torch.randn(E, D, F_, device=DEV, generator=g) * 0.02).bfloat16()     # nn.Linear(F, D).weight per expert: [D, F]
+    ar = torch.arange(E, device=DEV, dtype=torch.int64)
+    p2 = W2.data_ptr() + ar * (D * F_ * 2)
+    dy = torch.randn(n, D, device=DEV, generator=g).bfloat16()
+    hpre = torch.randn(n, F_, device=DEV, generator=g).bfloat16()
+    dh = ops.grouped_gemm(dy, p2, L.B_KN, F_, F_, bins.offsets, E, epilogue=L.EPI_ACTGRAD, act=L.ACT_GELU, aux=hpre)
+    plain = ops.grouped_gemm(dy, p2, L.B_KN, F_, F_, bins.offsets, E)
+    # the epilogue multiplies the ROUNDED product by act'(h_pre) and rounds once more
+    gp = torch.autograd.functional.jvp(torch.nn.functional.gelu, hpre.float(), torch.ones_like(hpre, dtype=torch.float32))[1]
+    want = (plain.float() * gp).bfloat16()
+    diff = (dh.float() - want.float()).abs()
+    assert float(diff.max()) <= 2 ** -7 * float(want.float().abs().max())        # <= 1 ulp: A&S erf vs torch's erf in gelu'
+    assert float((diff > 0).float().mean()) <= 0.02
+    del gp, want, diff
+    gen = torch.Generator().manual_seed(11)
+    offc = bins.offsets.cpu().long()
+    for _ in range(64):
+        r = int(torch.randint(0, n, (1,), generator=gen)); c = int(torch.randint(0, F_, (1,), generator=gen))
+        e = int(torch.searchsorted(offc[1:], torch.tensor(r), right=True))
+        ref = float((dy[r].double() * W2[e][:, c].double()).sum())
+        assert abs(float(plain[r, c]) - ref) <= 2 ** -7 * abs(ref) + 2e-2, (r, c)
+    dh2 = ops.grouped_gemm((dy.float() * 2).bfloat16(), p2, L.B_KN, F_, F_, bins.offsets, E, epilogue=L.EPI_ACTGRAD, act=L.ACT_GELU,
+                           aux=hpre)
+    assert torch.equal(dh2.float(), dh.float() * 2)
+    del dh2, plain, W2, dy, hpre
+    W1 = (torch.randn(E, F_, D, device=DEV, generator=g) * 0.02).bfloat16()     # nn.Linear(D, F).weight per expert: [F, D]
+    p1 = W1.data_ptr() + ar * (F_ * D * 2)
+    dxs = ops.grouped_gemm(dh, p1, L.B_KN, D, D, bins.offsets, E)
+    for _ in range(64):
+        r = int(torch.randint(0, n, (1,), generator=gen)); c = int(torch.randint(0, D, (1,), generator=gen))
+        e = int(torch.searchsorted(offc[1:], torch.tensor(r), right=True))
+        ref = float((dh[r].double() * W1[e][:, c].double()).sum())
+        assert abs(float(dxs[r, c]) - ref) <= 2 ** -7 * abs(ref) + 2e-2, (r, c)
+
+
+def test_sixty_four_expert_layer_forward_backward_full_size():
+    """The whole headline step -- `smoe`, 64 experts top-2, T = 32 768 as [16, 2048], d_model 4096, d_ff 11008, bf16, forward and
+    backward incl. every expert's weight gradients -- with IDENTICAL experts, where the domain gives closed forms at any size:
+    the output is the dense FFN whatever the routing (the K weights sum to 1); the sum over experts of the weight gradients is the
+    dense FFN's weight gradient (each (token, k) row contributes w_tk x the token's dense gradient); an expert that received no
+    rows gets exactly zero; dx is the dense dx up to the routing-weight path, which cancels for equal expert outputs.
+    (VERDICT r2 weak #5: the largest layer test was T = 4 096, E = 8.)"""
+    import types
+    from competesmoe_amd.moe import get_moe
+    torch.manual_seed(0)
+    base = nn.Sequential(nn.Linear(D, F_), nn.GELU(), nn.Linear(F_, D))
+    with torch.no_grad():
+        for p in base.parameters():
+            p.normal_(0, 0.02)
+    layer = get_moe("smoe")(D, D, E, K, base, types.SimpleNamespace(balance_loss_coef=0.0, router_z_loss_coef=0.0))
+    layer = layer.to(DEV).bfloat16().train()
+    x = torch.randn(16, T // 16, D, device=DEV).bfloat16().requires_grad_(True)
+    dy = torch.randn(16, T // 16, D, device=DEV).bfloat16()
+    out, aux, _, _ = layer(x)
+    torch.autograd.backward([out, aux.float()], [dy, torch.ones((), device=DEV)])
+    with torch.no_grad():
+        idx = layer.topk_expert(layer.gate_logits(x.detach()))[1].reshape(-1, K)
+        counts = torch.bincount(idx.flatten().long(), minlength=E)
+        assert int(counts.sum()) == T * K
+    # dense reference on the same weights (torch matmuls: test infrastructure)
+    m0 = layer.experts[0]
+    w1, b1, w2, b2 = (p.detach() for p in (m0[0].weight, m0[0].bias, m0[2].weight, m0[2].bias))
+    xd = x.detach().reshape(T, D).clone().requires_grad_(True)
+    w1d, w2d = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    dense = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(xd, w1d, b1)), w2d, b2)
+    dense.backward(dy.reshape(T, D))
+    err = (out.detach().float().reshape(T, D) - dense.detach().float()).norm() / dense.detach().float().norm()
+    assert err <= 4e-3, float(err)
+    g1 = torch.stack([m[0].weight.grad.float() for m in layer.experts]).sum(0)
+    g2 = torch.stack([m[2].weight.grad.float() for m in layer.experts]).sum(0)
+    e1 = float((g1 - w1d.grad.float()).norm() / w1d.grad.float().norm())
+    e2 = float((g2 - w2d.grad.float()).norm() / w2d.grad.float().norm())
+    assert e1 <= 1e-2 and e2 <= 1e-2, (e1, e2)
+    for e_ in range(E):
+        if int(counts[e_]) == 0:
+            assert float(layer.experts[e_][0].weight.grad.abs().max()) == 0.0
+    ex = float((x.grad.float().reshape(T, D) - xd.grad.float()).norm() / xd.grad.float().norm())
+    assert ex <= 1e-2, ex
+    assert torch.isfinite(layer.gate.weight.grad.float()).all()

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.golden_util import load, args_of, rel_l2, max_rel
+from tests.golden_util import load, args_of, rel_l2, max_rel, unpack_experts, expert_keys, ACT_OF_KIND
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -54,6 +54,34 @@ def build_layer(fx):
         layer.prob_flips = fx["prob_flips"].to(DEV)
         layer.set_current_steps(3)
     return layer, dt
+
+
+def oracle_grads(fx, gate_idx, aff_idx):
+    """Gradients of the pinned CPU oracle (tests/test_oracle_golden.py: with the REFERENCE's indices it reproduces every fixture's
+    gradients) evaluated with the KERNEL's indices -- the reference for fixtures with rows where the reference's own scores tie
+    exactly, torch.topk's pick among equal values being unspecified and the kernel's rule being the lowest index (VERDICT r2
+    item 1a).  Returns (x_grad, {parameter name: grad})."""
+    from oracle import moe_oracle as O
+    m, args = fx["meta"], args_of(fx)
+    experts = unpack_experts(fx, requires_grad=True)
+    wg = fx["state"]["gate.weight"].clone().requires_grad_(True)
+    x = fx["x"].clone().requires_grad_(True)
+    act = ACT_OF_KIND[m["expert_kind"]]
+    gi = gate_idx.cpu().long().view(*x.shape[:-1], -1)
+    if m["moe_name"] in ("smoe_share", "deepseekv3"):
+        out, aux, _, _ = O.llava_shared_forward(x, wg, experts, act, m["K"], args, m["moe_name"], out_dim=m["Dout"], forced_idx=gi)
+    elif m["moe_name"] == "competesmoe":
+        ai = None if aff_idx is None else aff_idx.cpu().long().view(*x.shape[:-1], -1)
+        out, aux, _, _ = O.llava_competesmoe_forward(x, wg, experts, act, m["K"], args, m["competition"], out_dim=m["Dout"],
+                                                     forced_idx=gi, forced_aff_idx=ai)
+    else:
+        out, aux, _, _ = O.llava_smoe_forward(x, wg, experts, act, m["K"], args, out_dim=m["Dout"], forced_idx=gi)
+    ((out.float() * fx["dy"].float()).sum() + aux.float()).backward()
+    grads = {"gate.weight": wg.grad}
+    for i, ts in enumerate(experts):
+        for k, t in zip(expert_keys(m["expert_kind"], i), ts):
+            grads[k] = t.grad
+    return x.grad, grads
 
 
 def tols(dt):
@@ -129,7 +157,7 @@ def test_layer_matches_reference_golden(case, tag):
                 b = torch.gather(ga, -1, gai)[bad].sort(-1).values
                 assert torch.equal(a, b), "a row routed differently from the reference without an exact tie in its scores"
                 print(f"bf16 competition rows whose top-K differs from the reference's (exact ties only): {float(bad.float().mean()):.4f}")
-                assert bad.float().mean() <= 0.10
+                assert bad.float().mean() <= 0.06        # observed 6 of 128 rows = 0.047 on both bf16 competition fixtures
     if not fx["meta"]["competition"]:
         assert int((~rows_ok).sum()) <= 2
     o = out.detach().reshape(-1, out.shape[-1])[rows_ok]
@@ -145,16 +173,26 @@ def test_layer_matches_reference_golden(case, tag):
         assert abs(float(infor[k]) - float(v)) <= ((2e-5 if dt == torch.float32 else 5e-3) + 2 * slack) * max(1e-2, abs(float(v))), k
 
     ((out.float() * dy.float()).sum() + aux.float()).backward()
-    if bool(rows_ok.all()):
+    ref_xg, ref_g = fx["x_grad"], fx["grads"]
+    if not bool(rows_ok.all()):
+        # rows routed unlike the reference's run (exact ties of its own scores, checked above): the gradients are compared with
+        # the pinned oracle's under the KERNEL's indices, so no fixture's backward goes unchecked
+        ref_xg, ref_g = oracle_grads(fx, live_idx, aidx if fx["meta"]["competition"] else None)
+        # ... and, on the rows routed alike, still with the reference's own dx (the tied rows reach the others only through the
+        # batch-level auxiliary losses, whose coefficients are 1e-2: observed <= 2e-3)
+        xa = x.grad.reshape(-1, x.shape[-1])[rows_ok]
+        xb = fx["x_grad"].to(DEV).reshape(-1, x.shape[-1])[rows_ok]
+        assert rel_l2(xa, xb) <= 1e-2, rel_l2(xa, xb)
+    if True:
         # bf16 gradients (profiles/r02/parity_report.txt): expert parameters are the reference's bits, the gate's and x's agree to
         # 1.4e-4 / 2.3e-5 now that the renormalisation's denominator gradient is rounded where autograd rounds it (the K-sum is a
         # bf16 tensor, smoe.py:44).  The shared-expert layers add one more bf16 gradient stream into x, summed in the engine's
         # order: dx 2.8e-3 there.
         gl = 4 * rl if dt == torch.float32 else 5e-4
         gx = gl if (dt == torch.float32 or fx["meta"]["moe_name"] not in ("smoe_share", "deepseekv3")) else 4e-3
-        assert rel_l2(x.grad, fx["x_grad"].to(DEV)) <= gx, rel_l2(x.grad, fx["x_grad"].to(DEV))
+        assert rel_l2(x.grad, ref_xg.to(DEV)) <= gx, rel_l2(x.grad, ref_xg.to(DEV))
         for name, p in layer.named_parameters():
-            gg = fx["grads"].get(name)
+            gg = ref_g.get(name)
             if gg is None:
                 continue
             assert p.grad is not None, name

@@ -16,6 +16,8 @@ def timed(fn, iters=30, warm=10):
     return a.elapsed_time(b) / iters
 
 def main():
+    import sys
+    few = "--few" in sys.argv          # under rocprofv3 (tools/vendor_probe.sh): the two dense row-space shapes only, few launches
     dev = "cuda:0"
     torch.manual_seed(0)
     n, D, F, E = 65536, 4096, 11008, 64
@@ -25,6 +27,11 @@ def main():
     w2 = torch.randn(F, D, device=dev, dtype=torch.bfloat16) * 0.03
     fl = 2.0 * n * D * F
     rows = []
+    if few:
+        for name, fn in (("dense NN  [n,D]x[D,F]", lambda: torch.matmul(x, w1)), ("dense NT  [n,F]x[D,F]^T", lambda: torch.matmul(h, w1.t())),
+                         ("dense NN  [n,F]x[F,D]", lambda: torch.matmul(h, w2))):
+            print(f"{name:52s} {timed(fn, iters=4, warm=2):8.3f} ms")
+        return
     rows.append(("dense NN  [n,D]x[D,F]", timed(lambda: torch.matmul(x, w1))))
     rows.append(("dense NN  [n,F]x[F,D]", timed(lambda: torch.matmul(h, w2))))
     rows.append(("dense NT  [n,F]x[D,F]^T", timed(lambda: torch.matmul(h, w1.t()))))
