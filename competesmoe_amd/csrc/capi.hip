@@ -25,6 +25,11 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
                  const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
                  const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
                  hipStream_t st);
+bool gg4_rowspace_ok(int Kd);
+int gg4_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                 const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                 const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
+                 hipStream_t st);
 int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int32_t* offsets, int E, int Na, int Nb,
               void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st, const int32_t* xcd_order = nullptr);
 int gg8c_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int64_t ldb, void* const* copy_ptrs,
@@ -100,14 +105,16 @@ static int gemm_pref() {
   static int pref = -1;
   if (pref < 0) {
     const char* e = getenv("CSMOE_GEMM_KERNEL");
-    pref = (e && !strcmp(e, "v1")) ? 1 : (e && !strcmp(e, "v2")) ? 2 : 0;
+    pref = (e && !strcmp(e, "v1")) ? 1 : (e && !strcmp(e, "v2")) ? 2 : (e && !strcmp(e, "v4")) ? 4 : 0;
   }
   return pref;
 }
+// the one-wave-per-SIMD kernel (gemm_bf16_v4.hip) instead of v2 for a row-space launch v2 would take?
+static bool use_v4_rowspace(int Kd) { return gemm_pref() == 4 && gg4_rowspace_ok(Kd); }
 static bool use_v2_rowspace(int M, int N, int Kd) {
   int p = gemm_pref();
   if (p == 1) return false;
-  if (p == 2) return true;
+  if (p == 2 || p == 4) return true;
   return N >= 256 && Kd >= 128 && M >= 2048;
 }
 static bool use_v2_wgrad(int M, int Na, int Nb) {
@@ -281,8 +288,8 @@ int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, in
   hipStream_t st = (hipStream_t)stream;
   if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C ? C : C2)) {
     if (use_v2_rowspace(M, N, Kd))
-      return gg8_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
-                          nullptr, nullptr, st);
+      return (use_v4_rowspace(Kd) ? gg4_rowspace : gg8_rowspace)(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2,
+                                                                 aux, ldc, epilogue, act, nullptr, nullptr, st);
     return gg_fast_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
                             nullptr, nullptr, st);
   }

@@ -25,6 +25,21 @@ struct EpiArgs {
 constexpr int EPI_LD = 264;                         // staged row stride in bf16 elements (528 B: 16-byte aligned, 4 banks per row)
 constexpr int EPI_LDS_BYTES = 256 * EPI_LD * 2;     // 135,168 B
 
+// How a kernel's waves hold the 256x256 accumulator tile (lane = 16 g + i16; every f32x4 = 4 consecutive columns of one row):
+//   Lay8: 8 waves as 2 row halves x 4 column quarters, acc[4][8], 64x32 blocks interleaved over the four operand images
+//         (gemm_bf16_v2.hip, gemm_bf16_v2c.hip, gemm_fp8.hip);
+//   Lay4: 4 waves as 2 x 2, one wave per SIMD, acc[8][8] = a contiguous 128x128 quadrant (gemm_bf16_v4.hip).
+struct Lay8 {
+  static constexpr int THREADS = 512, NCB = 4, NRB = 8;
+  static __device__ __forceinline__ int m(int wm, int rb, int i16) { return (rb >> 2) * 128 + wm * 64 + (rb & 3) * 16 + i16; }
+  static __device__ __forceinline__ int n(int wn, int cb, int g) { return (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g; }
+};
+struct Lay4 {
+  static constexpr int THREADS = 256, NCB = 8, NRB = 8;
+  static __device__ __forceinline__ int m(int wm, int rb, int i16) { return wm * 128 + rb * 16 + i16; }
+  static __device__ __forceinline__ int n(int wn, int cb, int g) { return wn * 128 + cb * 16 + 4 * g; }
+};
+
 enum { EC_PLAIN = 0, EC_BIAS = 1, EC_BIAS_ACT = 2, EC_R32_ACT = 3, EC_ACTGRAD = 4, EC_ACTGRAD_RS = 5 };   // _RS: + per-row scale (C2 slot)
 constexpr int ACT_RT = -1;                          // activation chosen at run time (the rarer ones share one instantiation)
 
@@ -37,34 +52,42 @@ __device__ __forceinline__ void epi_act_bwd8(float (&h)[8], int act_rt) {
   if constexpr (ACT == ACT_RT) act_bwd8(h, act_rt); else act_bwd8(h, ACT);
 }
 
-template <int CLS, int ACT>
-__device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][8], char* smem, int row0, int rows, int tc0,
+template <int CLS, int ACT, typename LAY = Lay8>
+__device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[LAY::NCB][LAY::NRB], char* smem, int row0, int rows, int tc0,
                                         int wm, int wn, int lane) {
+  constexpr int RSTEP = LAY::THREADS / 32;     // rows one pass of the workgroup covers (32 threads x 8 columns per row)
+  constexpr int RPT = 256 / RSTEP;             // rows per thread: 16 (512 threads) / 32 (256 threads)
   bf16* stg = (bf16*)smem;
   const int g = lane >> 4, i16 = lane & 15;
   const int ec = (threadIdx.x & 31) * 8;       // this thread's 8 columns inside the 256-wide tile
-  const int er = threadIdx.x >> 5;             // 0..15
+  const int er = threadIdx.x >> 5;             // 0..RSTEP-1
   const int ncol = tc0 + ec;
   const bool col_ok = ncol < p.NC;
 
-  bf16x8 hq[16];
-  if constexpr (CLS == EC_ACTGRAD || CLS == EC_ACTGRAD_RS) {
-    if (col_ok) {
+  // rows go through in chunks of 16 per thread (one chunk for the 512-thread layout, two for the 256-thread one: a 32-row
+  // straight-line body times the 12 (variant, activation) instantiations was 1.3 MB of code and minutes of compile time)
+  constexpr int CH = 16, NCH = RPT / CH;
+  bf16x8 hq[CH];
+  float rs[CH];                                // EC_ACTGRAD_RS: this thread's row scales, fetched with the pre-activations
+  auto fetch_aux = [&](int h) {
+    if constexpr (CLS == EC_ACTGRAD || CLS == EC_ACTGRAD_RS) {
+      if (col_ok) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = er + 16 * i;
-        if (r < rows) hq[i] = *(const bf16x8*)((const bf16*)p.aux + (int64_t)(row0 + r) * p.ldc + ncol);
+        for (int i = 0; i < CH; ++i) {
+          const int r = er + RSTEP * (h * CH + i);
+          if (r < rows) hq[i] = *(const bf16x8*)((const bf16*)p.aux + (int64_t)(row0 + r) * p.ldc + ncol);
+        }
       }
     }
-  }
-  float rs[16];                                // EC_ACTGRAD_RS: this thread's 16 row scales, fetched with the pre-activations
-  if constexpr (CLS == EC_ACTGRAD_RS) {
+    if constexpr (CLS == EC_ACTGRAD_RS) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = er + 16 * i;
-      rs[i] = r < rows ? ((const float*)p.C2)[row0 + r] : 0.f;
+      for (int i = 0; i < CH; ++i) {
+        const int r = er + RSTEP * (h * CH + i);
+        rs[i] = r < rows ? ((const float*)p.C2)[row0 + r] : 0.f;
+      }
     }
-  }
+  };
+  fetch_aux(0);                                // before the staging: 16 loads in flight per thread while the tile goes to LDS
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if constexpr (CLS == EC_R32_ACT) {           // fp32 bias added to the ROUNDED product (cvmm + bias)
     if (p.bias && col_ok) {
@@ -76,8 +99,8 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][
 
   // ---- stage: accumulators (+ bf16 bias, added before the rounding as F.linear does) -> bf16 -> LDS
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
-    const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
+  for (int cb = 0; cb < LAY::NCB; ++cb) {
+    const int n = LAY::n(wn, cb, g);
     float b[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (CLS == EC_BIAS || CLS == EC_BIAS_ACT) {
       if (p.bias && tc0 + n < p.NC) {
@@ -87,8 +110,8 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][
       }
     }
 #pragma unroll
-    for (int rb = 0; rb < 8; ++rb) {
-      const int m = (rb >> 2) * 128 + wm * 64 + (rb & 3) * 16 + i16;
+    for (int rb = 0; rb < LAY::NRB; ++rb) {
+      const int m = LAY::m(wm, rb, i16);
       bf16x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -108,9 +131,12 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][
   // (cvmm.py:544) -- reduced over the 16 threads of the half by shuffles: every thread stays for them
   float* const dot_tab = (CLS == EC_ACTGRAD_RS) ? (float*)p.bias : nullptr;
   if (!col_ok && dot_tab == nullptr) return;
+#pragma unroll 1
+  for (int hc = 0; hc < NCH; ++hc) {
+  if (hc > 0) fetch_aux(hc);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int r = er + 16 * i;
+  for (int i = 0; i < CH; ++i) {
+    const int r = er + RSTEP * (hc * CH + i);
     if (r < rows) {
       bf16x8 o0 = *(const bf16x8*)(stg + r * EPI_LD + ec);
       const int64_t o = (int64_t)(row0 + r) * p.ldc + ncol;
@@ -163,6 +189,7 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][
       }
     }
   }
+  }
 }
 
 // The two affinity epilogues of the competition pass: y = round(acc + bias) is staged like every other variant, then
@@ -171,9 +198,10 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[4][
 //   GRAD = true : C[row][col] = round(g * sigmoid(y)) with g = aux[row] / N (aux: FP32 d aff, one per row), g rounded to bf16
 //                 first under flag bit 1.
 // flags (EpiArgs::act): bit 0 precise exp / log1p, bit 1 round every softplus / product to bf16 first (x.dtype tensor ops).
-template <bool GRAD>
-__device__ __forceinline__ void epi_softplus(const EpiArgs& p, const f32x4 (&acc)[4][8], char* smem, int row0, int rows, int tc0,
+template <bool GRAD, typename LAY = Lay8>
+__device__ __forceinline__ void epi_softplus(const EpiArgs& p, const f32x4 (&acc)[LAY::NCB][LAY::NRB], char* smem, int row0, int rows, int tc0,
                                              int wm, int wn, int lane) {
+  constexpr int RSTEP = LAY::THREADS / 32, RPT = 256 / RSTEP;
   bf16* stg = (bf16*)smem;
   const int g = lane >> 4, i16 = lane & 15;
   const int ec = (threadIdx.x & 31) * 8, er = threadIdx.x >> 5;
@@ -181,8 +209,8 @@ __device__ __forceinline__ void epi_softplus(const EpiArgs& p, const f32x4 (&acc
   const bool col_ok = ncol < p.NC;
   const bool precise = p.act & 1, rnd = p.act & 2;
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
-    const int n = (cb >> 1) * 128 + wn * 32 + (cb & 1) * 16 + 4 * g;
+  for (int cb = 0; cb < LAY::NCB; ++cb) {
+    const int n = LAY::n(wn, cb, g);
     float b[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && tc0 + n < p.NC) {
       const bf16x4 b4 = *(const bf16x4*)((const bf16*)p.bias + tc0 + n);
@@ -190,8 +218,8 @@ __device__ __forceinline__ void epi_softplus(const EpiArgs& p, const f32x4 (&acc
       for (int j = 0; j < 4; ++j) b[j] = (float)b4[j];
     }
 #pragma unroll
-    for (int rb = 0; rb < 8; ++rb) {
-      const int m = (rb >> 2) * 128 + wm * 64 + (rb & 3) * 16 + i16;
+    for (int rb = 0; rb < LAY::NRB; ++rb) {
+      const int m = LAY::m(wm, rb, i16);
       bf16x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = p.bias ? (bf16)(acc[cb][rb][j] + b[j]) : (bf16)acc[cb][rb][j];
@@ -203,8 +231,8 @@ __device__ __forceinline__ void epi_softplus(const EpiArgs& p, const f32x4 (&acc
   asm volatile("" ::: "memory");
   const int nt = tc0 >> 8;
 #pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int r = er + 16 * i;                      // the two rows of a wave go through the loop together (shuffles below)
+  for (int i = 0; i < RPT; ++i) {
+    const int r = er + RSTEP * i;                   // the two rows of a wave go through the loop together (shuffles below)
     const bf16x8 o0 = *(const bf16x8*)(stg + r * EPI_LD + ec);
     if constexpr (!GRAD) {
       float s = 0.f;
@@ -230,28 +258,29 @@ __device__ __forceinline__ void epi_softplus(const EpiArgs& p, const f32x4 (&acc
   }
 }
 
-template <int CLS>
-__device__ __forceinline__ void epi_by_act(const EpiArgs& p, const f32x4 (&acc)[4][8], char* smem, int row0, int rows, int tc0,
+template <int CLS, typename LAY = Lay8>
+__device__ __forceinline__ void epi_by_act(const EpiArgs& p, const f32x4 (&acc)[LAY::NCB][LAY::NRB], char* smem, int row0, int rows, int tc0,
                                            int wm, int wn, int lane) {
-  if (p.act == CSMOE_ACT_GELU) epi_run<CLS, CSMOE_ACT_GELU>(p, acc, smem, row0, rows, tc0, wm, wn, lane);
-  else if (p.act == CSMOE_ACT_RELU) epi_run<CLS, CSMOE_ACT_RELU>(p, acc, smem, row0, rows, tc0, wm, wn, lane);
-  else epi_run<CLS, ACT_RT>(p, acc, smem, row0, rows, tc0, wm, wn, lane);
+  if (p.act == CSMOE_ACT_GELU) epi_run<CLS, CSMOE_ACT_GELU, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane);
+  else if (p.act == CSMOE_ACT_RELU) epi_run<CLS, CSMOE_ACT_RELU, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane);
+  else epi_run<CLS, ACT_RT, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane);
 }
 
-// Called by all 512 threads after the K-loop's LDS traffic has drained (the staging tile overlays the operand images).
-__device__ __forceinline__ void rowspace_epilogue(const EpiArgs& p, const f32x4 (&acc)[4][8], char* smem, int row0, int rows,
+// Called by all of the workgroup's threads after the K-loop's LDS traffic has drained (the staging tile overlays the operand images).
+template <typename LAY = Lay8>
+__device__ __forceinline__ void rowspace_epilogue(const EpiArgs& p, const f32x4 (&acc)[LAY::NCB][LAY::NRB], char* smem, int row0, int rows,
                                                   int tc0, int wm, int wn, int lane) {
   switch (p.epilogue) {
-    case CSMOE_EPI_ACTGRAD: epi_by_act<EC_ACTGRAD>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
-    case CSMOE_EPI_ACTGRAD_ROWSCALE: epi_by_act<EC_ACTGRAD_RS>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
-    case CSMOE_EPI_SOFTPLUS_ROWSUM: epi_softplus<false>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
-    case CSMOE_EPI_SOFTPLUS_GRAD: epi_softplus<true>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
-    case CSMOE_EPI_ROUND_BIAS32_ACT: epi_by_act<EC_R32_ACT>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
-    case CSMOE_EPI_BIAS_ACT: epi_by_act<EC_BIAS_ACT>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_ACTGRAD: epi_by_act<EC_ACTGRAD, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_ACTGRAD_ROWSCALE: epi_by_act<EC_ACTGRAD_RS, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_SOFTPLUS_ROWSUM: epi_softplus<false, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_SOFTPLUS_GRAD: epi_softplus<true, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_ROUND_BIAS32_ACT: epi_by_act<EC_R32_ACT, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    case CSMOE_EPI_BIAS_ACT: epi_by_act<EC_BIAS_ACT, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
     case CSMOE_EPI_BIAS:
-      if (p.bias) { epi_run<EC_BIAS, 0>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break; }
+      if (p.bias) { epi_run<EC_BIAS, 0, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break; }
       [[fallthrough]];
-    default: epi_run<EC_PLAIN, 0>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
+    default: epi_run<EC_PLAIN, 0, LAY>(p, acc, smem, row0, rows, tc0, wm, wn, lane); break;
   }
 }
 

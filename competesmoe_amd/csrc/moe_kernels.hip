@@ -72,7 +72,14 @@ __global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scor
     float dden = -dot / (denom * denom);
     if (round_sum_bf16 && (mode == CSMOE_SEL_SOFTMAX || mode == CSMOE_SEL_TOPK_SIGMOID)) dden = (float)(bf16)dden;
     dv = mydw / denom + dden;
-    if (mode == CSMOE_SEL_SIGMOID) dv *= myv * (1.f - myv);
+    if (mode == CSMOE_SEL_SIGMOID) {
+      // deepseekv3 under autocast (deepseekv3.py:147-151): the K sigmoids are a bf16 TENSOR used twice -- as the numerator and,
+      // through the fp32-policy `sum`, in the denominator -- so autograd hands it two gradients, each rounded to bf16 (the quotient's
+      // backward; the cast in front of the sum), adds them in bf16, and sigmoid's backward multiplies the rounded sum (one more
+      // rounding at the store below).  Without these three roundings d w_gate was 4.6e-3 off the reference's (fp32 runs: no-ops).
+      dv = round_dt(round_dt(mydw / denom, dtype) + round_dt(dden, dtype), dtype);
+      dv *= myv * (1.f - myv);
+    }
     if (mode == CSMOE_SEL_TOPK_SIGMOID) dv *= myv * (1.f - myv) / sel_param;
   }
   // scatter dv to the expert positions; softmax-path gradient

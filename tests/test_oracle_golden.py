@@ -378,11 +378,16 @@ def test_pretrain_smoe_perturbed(tag):
     r = 1e-5 if tag == "fp32" else 2e-4
     assert rel_l2(o2[~bad], g2[~bad]) <= r
     assert abs(float(reg) - float(fx["reg_loss"]["mlp_ebalance"])) <= 1e-6
-    if not bool(bad.any()):
-        ((out.float() * fx["dy"]).sum() + reg.float()).backward()
-        assert rel_l2(x.grad, fx["x_grad"]) <= 4 * r
-        for k, p in (("keys", keys), ("values", values), ("expert_sel", esel), ("expert_embeddings", emb)):
-            assert rel_l2(p.grad, fx["grads"][k]) <= 4 * r, (k, rel_l2(p.grad, fx["grads"][k]))
+    # gradients with the indices the reference's own torch.topk returned (fx["selected_experts"]): pins the restatement's backward
+    # on the bf16 fixture too, where exact ties of the bf16 softmax values make the selection itself ambiguous
+    gi = fx["selected_experts"].long()
+    w = torch.softmax(torch.gather(sm, -1, gi), dim=-1)
+    out = O.pretrain_ffn(x, gi, w, keys, values, "relu", op)
+    assert rel_l2(out, fx["output"]) <= r, rel_l2(out, fx["output"])
+    ((out.float() * fx["dy"]).sum() + reg.float()).backward()
+    assert rel_l2(x.grad, fx["x_grad"]) <= 4 * r, rel_l2(x.grad, fx["x_grad"])
+    for k, p in (("keys", keys), ("values", values), ("expert_sel", esel), ("expert_embeddings", emb)):
+        assert rel_l2(p.grad, fx["grads"][k]) <= 4 * r, (k, rel_l2(p.grad, fx["grads"][k]))
 
 
 @pytest.mark.parametrize("tag", TAGS)

@@ -59,7 +59,15 @@ def oracle_grads(fx, idx):
     x = fx["x"].clone().requires_grad_(True)
     ps = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.is_floating_point()}
     idx = idx.cpu().long().view(*x.shape[:-1], -1)
-    if m["moe_name"] in ("deepseekv2", "deepseekv3"):
+    if m["moe_name"] == "smoe_perturbed":
+        # cosine gate over the renormalised expert embeddings (smoe_perturbed.py:148-197); the layer renormalises the parameter in
+        # place under no_grad, so its gradient is the gradient of the renormalised values
+        ps["expert_embeddings"] = O.renorm_embeddings(st["expert_embeddings"]).clone().requires_grad_(True)
+        lg = O.perturbed_gate(x, ps["expert_sel"], ps["expert_embeddings"], op if m["bf16"] else None)
+        sm = torch.softmax((lg / 0.3).float(), -1).to(x.dtype)
+        w = torch.softmax(torch.gather(sm, -1, idx), dim=-1)
+        out = O.pretrain_ffn(x, idx, w, ps["keys"], ps["values"], "relu", op)
+    elif m["moe_name"] in ("deepseekv2", "deepseekv3"):
         out, lg = O.pretrain_deepseek_forward(x, ps["w_gate"], ps["keys"], ps["values"], ps["keys_shared"], ps["values_shared"],
                                               m["K"], m["moe_name"], op, x.dtype, forced_idx=idx)
     else:
