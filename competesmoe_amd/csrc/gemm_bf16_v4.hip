@@ -141,16 +141,16 @@ __device__ __forceinline__ void read_r0_all(LoopState& st, std::integer_sequence
 // What the vendor's hand-written 256x256x64 kernel does (disassembly of hipBLASLt's Custom_Cijk_Alik_Bljk_..._MT256x256x64: 4 waves,
 // 128 x 128 per wave, 16 `buffer_load_dwordx4 ... lds` + 32 ds_read_b128 + 3 s_barrier per wave and K-tile, all four fragment sets in
 // registers, 92 % MFMA-busy): no VGPR staging, no LDS store instructions, no address VALU.  A slot half can only be re-filled once
-// EVERY wave has read it, so the fragments of K-step 1 are read early and the K-tile takes three barriers:
-//   I =  0..14 (even)   read the 8 row fragments of K-step 1 (slot CUR)
-//   I = 20              lgkmcnt(0) + barrier 1: slot CUR's row images are free (their K-step 0 halves were read a K-tile ago)
-//   I = 22..52 (even)   8 x { DMA row piece k of K-tile s+2 -> slot CUR ; read column fragment k of K-step 1 }
-//   I = 58              lgkmcnt(0) + barrier 2: slot CUR's column images are free
-//   I = 60..88 (x4)     DMA the 8 column pieces of K-tile s+2 -> slot CUR
-//   I = 92              vmcnt(16) + barrier 3: only K-tile s+2's 16 pieces are still in flight, K-tile s+1 is in slot NXT for everyone
-//   I = 96..126 (even)  read the 16 fragments of K-step 0 of K-tile s+1 (slot NXT)
+// EVERY wave has read it, so all of K-step 1's fragments are read early (every wave then holds the whole K-tile in registers) and the K-tile takes two barriers:
+//   I =  0..31          read the 16 fragments of K-step 1 (slot CUR), one every other slot
+//   I = 34              lgkmcnt(0) + barrier: every wave holds all of K-tile s in registers, slot CUR is free
+//   I = 36 + 5 k + W    DMA piece k (< 16) of K-tile s+2 -> slot CUR: the CU's 64 pieces spread evenly over 3/4 of the K-tile (in
+//                       two bursts of 8 between three barriers the address path was offered twice what it moves and blocked the
+//                       issuing waves: +1.1 ms on a 3.0 ms MFMA stream, tools/v4_ablate.sh)
+//   I = 94              vmcnt(pieces issued so far) + barrier: K-tile s+1, issued a K-tile ago, is in slot NXT for everyone
+//   I = 96..127         read the 16 fragments of K-step 0 of K-tile s+1 (slot NXT)
 #ifndef CSMOE_V4_ABL
-#define CSMOE_V4_ABL 0      // diagnostic twins (tools/v4_ablate.sh): bit 0 = no fragment reads in the loop, bit 1 = no LDS-DMA in the loop
+#define CSMOE_V4_ABL 0      // diagnostic twins (tools/v4_ablate.sh): bit 0 = no fragment reads in the loop, bit 1 = no LDS-DMA in the loop, bit 2 = no landing wait (wrong results: timing only)
 #endif
 template <int I, int SL>
 __device__ __forceinline__ void dma_piece4(LoopState& st, int tile) {
@@ -170,24 +170,27 @@ __device__ __forceinline__ void slot_dma(f32x4 (&acc)[8][8], LoopState& st, int 
   constexpr int gi = I >> 3, ks = gi >> 3, cb = gi & 7, rb = I & 7;
   constexpr bool RD = !(CSMOE_V4_ABL & 1), DM = !(CSMOE_V4_ABL & 2);
   constexpr int P = W & 1;                     // read slots: parity
-  constexpr int D = W, R2 = (W + 2) & 3;       // DMA slots: W of every 4; the column-fragment reads beside them two slots away
+  constexpr int D0 = 36 + W, DSTEP = 5;        // DMA piece k at slot D0 + 5 k: the 64 pieces of a K-tile spread over 3/4 of it
+  constexpr int LAND = 94;                     // slot of the landing barrier
   if constexpr (rb < RBN) {
     if constexpr (ks == 0) mfma_acc(acc[cb][rb], st.fc0[cb], st.fr0[rb]);
     else                   mfma_acc(acc[cb][rb], st.fc1[cb], st.fr1[rb]);
   }
-  if constexpr (RD && I < 16 && (I & 1) == P && (I >> 1) < RBN) st.fr1[I >> 1] = read_r<CUR, 1, (I >> 1)>(st);
-  if constexpr (I == 20 || I == 58) {
+  if constexpr (RD && I < 32 && (I & 1) == P) {                // K-step 1's 16 fragments, early: slot CUR is free after them
+    constexpr int k = I >> 1;
+    if constexpr (k < 8) { if constexpr (k < RBN) st.fr1[k] = read_r<CUR, 1, k>(st); }
+    else st.fc1[k - 8] = read_c<COLK, CUR, 1, (k - 8)>(st);
+  }
+  if constexpr (I == 34) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  if constexpr (DM && I >= 22 + D && I <= 50 + D && ((I - 22 - D) & 3) == 0) dma_piece4<((I - 22 - D) >> 2), CUR>(st, t2);
-  if constexpr (RD && I >= 22 + R2 && I <= 50 + R2 && ((I - 22 - R2) & 3) == 0)
-    st.fc1[(I - 22 - R2) >> 2] = read_c<COLK, CUR, 1, ((I - 22 - R2) >> 2)>(st);
-  if constexpr (DM && I >= 60 + D && I <= 88 + D && ((I - 60 - D) & 3) == 0) dma_piece4<8 + ((I - 60 - D) >> 2), CUR>(st, t2);
-  if constexpr (I == 92) {
-    if constexpr (DM) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  if constexpr (I == LAND) {                                   // K-tile s+1 (issued a K-tile ago) landed, for every wave
+    constexpr int issued = (LAND - D0 + DSTEP - 1) / DSTEP;    // this K-tile's pieces issued so far (slots < LAND) stay in flight
+    if constexpr (DM && !(CSMOE_V4_ABL & 4)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(issued) : "memory");
     __builtin_amdgcn_s_barrier();
   }
+  if constexpr (DM && I >= D0 && I <= D0 + 15 * DSTEP && ((I - D0) % DSTEP) == 0) dma_piece4<((I - D0) / DSTEP), CUR>(st, t2);
   if constexpr (RD && I >= 96 && (I & 1) == P) {
     constexpr int k = (I - 96) >> 1;
     if constexpr (k < 8) { if constexpr (k < RBN) st.fr0[k] = read_r<NXT, 0, k>(st); }

@@ -72,6 +72,14 @@ __global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scor
     float dden = -dot / (denom * denom);
     if (round_sum_bf16 && (mode == CSMOE_SEL_SOFTMAX || mode == CSMOE_SEL_TOPK_SIGMOID)) dden = (float)(bf16)dden;
     dv = mydw / denom + dden;
+    if (mode == CSMOE_SEL_RAW) {
+      // competition step (competesmoe.py:253-255): `weights` is an x.dtype TENSOR taken from the affinities and used twice -- as the
+      // numerator and in the K-sum -- so under bf16 it receives its own gradient rounded (the weighted sum's backward hands back a
+      // bf16 tensor), then two bf16 gradients (quotient, sum), added in bf16; the result is scattered into d affinity.  fp32: no-ops.
+      const float dwr = round_dt(mydw, dtype);
+      const float ddr = round_dt(-wave_sum(dwr * myv) / (denom * denom), dtype);
+      dv = round_dt(round_dt(dwr / denom, dtype) + ddr, dtype);
+    }
     if (mode == CSMOE_SEL_SIGMOID) {
       // deepseekv3 under autocast (deepseekv3.py:147-151): the K sigmoids are a bf16 TENSOR used twice -- as the numerator and,
       // through the fp32-policy `sum`, in the denominator -- so autograd hands it two gradients, each rounded to bf16 (the quotient's
@@ -109,7 +117,9 @@ __global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scor
 #pragma unroll
   for (int v = 0; v < VPL; ++v) {
     int e = lane + 64 * v;
-    if (e < E) store_score(dscores, base + e, p[v] * (g[v] - inner) + direct[v], dtype);
+    // SEL_RAW: the scores feed the fp32 softmax AND the top-K values: two gradient tensors in the scores' dtype, added in that dtype
+    const float sp = p[v] * (g[v] - inner);
+    if (e < E) store_score(dscores, base + e, mode == CSMOE_SEL_RAW ? round_dt(sp, dtype) + direct[v] : sp + direct[v], dtype);
   }
 }
 
