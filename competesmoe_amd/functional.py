@@ -403,8 +403,10 @@ def _grouped_wgrad(a: torch.Tensor, b: torch.Tensor, bins, E: int, pd) -> torch.
     return ops.sum_partials(part.view(E * P, Na * Nb), E, P, pd).view(E, Na, Nb)
 
 
-def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool, dy_extra=None):
-    """Returns dx2, dw, (gW1 [E,..], gb1 [E,F]|None, gW2 [E,..], gb2 [E,Dout]|None)."""
+def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool, dy_extra=None, dx_add=None):
+    """Returns dx2, dw, (gW1 [E,..], gb1 [E,F]|None, gW2 [E,..], gb2 [E,Dout]|None).
+    `dx_add`: a callable dw -> [T, D] tensor (or None) added to dx INSIDE the gather-sum of the binned rows (csmoe_dispatch_rows_bwd's
+    `add` input): the gate-path gradient of x, which depends on this function's dw (SparseMoEModules)."""
     if saved is None:
         raise RuntimeError("competesmoe_amd: the MoE layer's saved activations were freed by the first backward pass "
                            "(they are released early to bound memory); a second backward through the same graph "
@@ -465,7 +467,7 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
     dx2 = None
     if need_dx:
         dxs = ops.grouped_gemm(dh, tab.w1_ptrs, _flip(tab.layout), ld1, tab.D, bins.offsets, E)
-        dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
+        dx2 = ops.dispatch_rows_bwd(dxs, bins, T, add=None if dx_add is None else dx_add(dw))
     return dx2, dw, grads
 
 
@@ -498,6 +500,79 @@ class MoEFFNModules(torch.autograd.Function):
             seq = [gW1] + ([gb1] if gb1 is not None else []) + [gW2] + ([gb2] if gb2 is not None else [])
             pg = [g[e] for g in seq for e in range(E)]
         return (dx2, dw, None, None, None, *pg)
+
+
+class SparseMoEModules(torch.autograd.Function):
+    """GateSelect + MoEFFNModules as ONE node -- router_policy / topk_expert + compute_moe of a sparse step (moe_model/model/moe/
+    smoe.py:39-64, moe.py:113-213) -- so that the two gradient streams of x, through the gate and through the experts, meet inside
+    the gather-sum of the binned rows (`csmoe_dispatch_rows_bwd(..., add)`: round(round(sum_k dxs) + dx_gate), the bits of autograd's
+    separate accumulation pass) instead of in an elementwise add over [T, D] (0.13 ms and 0.8 GB at the headline shape).
+    Returns (out, logits, softmax fp32, idx int32, w fp32): the losses are built on the last four outside, their gradients come
+    back here.  Backward: expert path (which yields d w), then the selection's backward with d w and the losses' gradients, the
+    gate's two products, and the gather-sum with the gate-path dx as its `add` input."""
+
+    @staticmethod
+    def forward(ctx, x2, w_gate, K: int, mode: int, round_sum_bf16: bool, tab: ExpertTable, combine_mode: int, *params):
+        x2 = x2.contiguous()
+        wg = w_gate.contiguous()
+        if wg.dtype != x2.dtype:
+            wg = wg.to(x2.dtype)
+        logits, sm, idx, w = ops.gate_select(x2, wg, K, mode, round_sum_bf16, want_softmax=True)
+        out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, None)
+        ctx.save_for_backward(x2, wg, logits, sm, idx, w)
+        ctx.cfg = (K, mode, round_sum_bf16)
+        ctx.w_dtype = w_gate.dtype
+        ctx.tab, ctx.saved = tab, saved
+        ctx.n_params = len(params)
+        ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
+        return out, logits, sm, idx, w
+
+    @staticmethod
+    def backward(ctx, dout, dlogits, dsm, _didx, dw_ext):
+        x2, wg, logits, sm, idx, w = ctx.saved_tensors
+        K, mode, rb = ctx.cfg
+        tab = ctx.tab
+        need_x, need_wg = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_params = any(ctx.needs_input_grad[7:])
+        small = ops.gate_bwd_small_ok(x2.shape[1], wg.shape[0], x2.dtype)
+        box = {}
+
+        def gate_path(dw):
+            """d logits from the selection's backward (+ the losses' own gradient on the logits); the gate-path dx (or None)."""
+            if dw_ext is not None:
+                dw = dw_ext.contiguous().float() if dw is None else dw + dw_ext
+            ds = None
+            if dw is not None or dsm is not None:
+                ds = ops.router_select_bwd(logits, K, mode, rb, sm, idx, w, None if dw is None else dw.contiguous().float(),
+                                           None if dsm is None else dsm.contiguous().float())
+            if dlogits is not None:
+                ds = dlogits.contiguous() if ds is None else ds + dlogits
+            box["ds"] = ds
+            if ds is None or not need_x:
+                return None
+            return ops.gate_bwd_dx(ds, wg) if small else ops.dense_gemm(ds, wg, L.B_KN)
+
+        if dout is None:                         # only the losses reach x: no expert path
+            ctx.saved = None
+            dx2 = gate_path(None)
+            grads = None
+        else:
+            want_dw = need_x or need_wg          # d w only matters through the gate
+            dx2, dw, grads = _ffn_backward(dout, w, tab, ctx.saved, need_x, want_dw, need_params, dx_add=gate_path if need_x else None)
+            ctx.saved = None
+            if not need_x:
+                gate_path(dw)
+        dwg = None
+        if need_wg and box.get("ds") is not None:
+            dwg = _gate_wgrad(box["ds"], x2, ctx.w_dtype, small)
+        pg: List[Optional[torch.Tensor]] = [None] * ctx.n_params
+        if grads is not None:
+            gW1, gb1, gW2, gb2 = grads
+            E = tab.E
+            seq = [gW1] + ([gb1] if gb1 is not None else []) + [gW2] + ([gb2] if gb2 is not None else [])
+            pg = [g[e] for g in seq for e in range(E)]
+        return (dx2, dwg, None, None, None, None, None, *pg)
 
 
 class _SlotMap:

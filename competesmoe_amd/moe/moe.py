@@ -11,6 +11,7 @@ What changed underneath: `compute_moe` is one binning pass + dispatch + two grou
 from __future__ import annotations
 
 import copy
+import os
 from typing import List, NamedTuple, Optional, Tuple
 
 import torch
@@ -19,7 +20,7 @@ import torch.nn as nn
 from .. import _lib as L
 from ..functional import (CompetitionAffinity, ExpertTable, GateLogits, GateSelect, MoEFFNModules, MoEFFNModulesResidual,
                           MoEFFNModulesSlots, RouterSelect, DenseFFN, DiversityLoss,
-                          RouterAux)
+                          RouterAux, SparseMoEModules)
 from .. import ops
 
 
@@ -189,6 +190,22 @@ class MoeLayer(nn.Module):
         logits = self.gate_logits(x)
         w, idx, sm = self.topk_expert(gate_logits=logits)
         return Route(logits, sm, idx, w)
+
+    def _route_and_compute(self, x):
+        """`_route` + `compute_moe` of a sparse step.  Where the one-pass router takes the shape and nothing else is hooked in (no
+        logits / residual handed over by the block around the layer) both run as ONE autograd node (SparseMoEModules): same bits,
+        and the gate-path and expert-path gradients of x meet inside the backward's gather-sum instead of in an autograd add."""
+        B, N, D = x.shape
+        K, E = self.num_selected, self.gate.weight.shape[0]
+        x2 = x.reshape(B * N, D)
+        if (os.environ.get("CSMOE_FUSED_STEP", "1") != "0" and getattr(self, "_pre_logits", None) is None
+                and getattr(self, "_residual", None) is None and E == len(self.experts) and ops.gate_select_ok(x2, self.gate.weight, K)):
+            tab, params = self._expert_table(E, x.dtype, x.device)
+            out, logits, sm, idx, w = SparseMoEModules.apply(x2, self.gate.weight, K, L.SEL_SOFTMAX, x.dtype == torch.bfloat16, tab,
+                                                             L.COMBINE_SEQ, *params)
+            return Route(logits.view(B, N, E), sm.view(B, N, E), idx.view(B, N, K), w.view(B, N, K)), out.view(B, N, out.shape[-1])
+        route = self._route(x)
+        return route, self.compute_moe(route.idx, route.w, None, x)
 
     def _router_aux(self, route: "Route", wanted: bool, like: torch.Tensor, keep_metrics: bool = False):
         """(auxiliary loss, infor_aux) of a sparse step: balance + z-loss when `wanted` (smoe.py:51-62), else a zero and {}.

@@ -17,7 +17,6 @@ class SMoeLayer(MoeLayer):
     def forward(self, x, return_id_experts=False, is_vision=False):
         """(output, auxiliary_loss, None, infor_aux) -- smoe.py:39-64."""
         self.is_vision = is_vision
-        route = self._route(x)
-        output = self.compute_moe(route.idx, route.w, None, x)
+        route, output = self._route_and_compute(x)
         aux, infor_aux = self._router_aux(route, x.requires_grad or return_id_experts, x, keep_metrics=True)
         return output, aux, None, infor_aux

@@ -275,7 +275,10 @@ def test_layer_matches_reference_golden(case, tag):
             if gg is None:
                 continue
             assert p.grad is not None, name
-            assert rel_l2(p.grad, gg.to(DEV)) <= gl, (name, rel_l2(p.grad, gg.to(DEV)))
+            # competition steps: every expert parameter receives TWO bf16 gradients (the dense pass and the sparse recompute) whose
+            # dense part carries the routing-weight gradient discussed above: 5.6e-4 observed, bound = north_star's 1e-3
+            gp = 1e-3 if (dt == torch.bfloat16 and fx["meta"]["competition"]) else gl
+            assert rel_l2(p.grad, gg.to(DEV)) <= gp, (name, rel_l2(p.grad, gg.to(DEV)))
 
     # --- no-grad forward: aux is zero, same output
     with torch.no_grad():
@@ -352,3 +355,41 @@ def test_layer_under_gradient_checkpointing(case, reentrant):
     assert set(p1) == set(p2)
     for n in p1:
         assert torch.equal(p1[n], p2[n]), n
+
+
+@pytest.mark.parametrize("case", ["smoe", "smoe_siglip", "smoe_proj"])
+def test_sparse_step_as_one_autograd_node_is_bit_identical_to_the_two_node_form(case, monkeypatch):
+    """`smoe` runs gate + selection + dispatch / FFN / combine as ONE autograd node (SparseMoEModules), so that the gate-path and the
+    expert-path gradient of x meet inside the backward's gather-sum (csmoe_dispatch_rows_bwd's `add`) instead of in an elementwise
+    add; CSMOE_FUSED_STEP=0 keeps GateSelect + MoEFFNModules as two nodes.  Outputs, losses and every gradient: the same bits."""
+    from competesmoe_amd import functional as Fn
+    fx = load(f"llava_{case}_bf16")
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CSMOE_FUSED_STEP", flag)
+        calls = []
+        orig = Fn.SparseMoEModules.forward
+
+        def spy(ctx, *a):
+            calls.append(1)
+            return orig(ctx, *a)
+        monkeypatch.setattr(Fn.SparseMoEModules, "forward", staticmethod(spy))
+        layer, dt = build_layer(fx)
+        x = fx["x"].to(DEV).requires_grad_(True)
+        out, aux, _, info = layer(x)
+        ((out.float() * fx["dy"].to(DEV).float()).sum() + aux.float()).backward()
+        assert bool(calls) == (flag == "1")
+        res.append((out.detach().clone(), float(aux), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None}))
+        monkeypatch.setattr(Fn.SparseMoEModules, "forward", staticmethod(orig))
+    (o1, a1, g1, p1), (o0, a0, g0, p0) = res
+    assert torch.equal(o1, o0) and a1 == a0 and torch.equal(g1, g0) and set(p1) == set(p0)
+    for n in p1:
+        assert torch.equal(p1[n], p0[n]), n
+    # the gate may be frozen (no d w needed through it): x still gets the expert path, the gate gets nothing
+    monkeypatch.setenv("CSMOE_FUSED_STEP", "1")
+    layer, dt = build_layer(fx)
+    layer.gate.weight.requires_grad_(False)
+    x = fx["x"].to(DEV).requires_grad_(True)
+    out, aux, _, _ = layer(x)
+    (out.float() * fx["dy"].to(DEV).float()).sum().backward()
+    assert layer.gate.weight.grad is None and torch.isfinite(x.grad.float()).all()
