@@ -25,7 +25,7 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
                  const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
                  const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
                  hipStream_t st);
-bool gg4_rowspace_ok(int Kd);
+bool gg4_rowspace_ok(int Kd, int b_layout);
 int gg4_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
                  const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
                  const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
@@ -109,13 +109,27 @@ static int gemm_pref() {
   }
   return pref;
 }
-// the one-wave-per-SIMD kernel (gemm_bf16_v4.hip) instead of v2 for a row-space launch v2 would take?
-static bool use_v4_rowspace(int Kd) { return gemm_pref() == 4 && gg4_rowspace_ok(Kd); }
+// Row-space 256x256 kernel for a launch the v2 rule accepts: the one-wave-per-SIMD kernel (gemm_bf16_v4.hip) for K-contiguous
+// weights when K is a whole number of K-tile pairs, else the 8-wave kernel.  `kernel` = the caller's CSMOE_KERNEL_* request; CSMOE_GEMM_KERNEL=v2|v4 (A/B runs,
+// read once) overrides the automatic choice.
 static bool use_v2_rowspace(int M, int N, int Kd) {
   int p = gemm_pref();
   if (p == 1) return false;
   if (p == 2 || p == 4) return true;
   return N >= 256 && Kd >= 128 && M >= 2048;
+}
+static bool use_v4_rowspace(int Kd, int b_layout, int kernel) {
+  if (!gg4_rowspace_ok(Kd, b_layout)) return false;
+  if (kernel == CSMOE_KERNEL_V2) return false;
+  if (kernel == CSMOE_KERNEL_V4) return true;
+  return gemm_pref() != 2;
+}
+typedef int (*rowspace_fn)(const void*, int64_t, const void* const*, int, int64_t, const void* const*, const int32_t*, int, int, int, int,
+                           void*, void*, const void*, int64_t, int, int, const void*, const void*, hipStream_t);
+static rowspace_fn pick_rowspace(int M, int N, int Kd, int b_layout, int kernel) {
+  const bool big = (kernel == CSMOE_KERNEL_V2 || kernel == CSMOE_KERNEL_V4) ? (N >= 256 && Kd >= 128) : use_v2_rowspace(M, N, Kd);
+  if (!big) return gg_fast_rowspace;
+  return use_v4_rowspace(Kd, b_layout, kernel) ? gg4_rowspace : gg8_rowspace;
 }
 static bool use_v2_wgrad(int M, int Na, int Nb) {
   int p = gemm_pref();
@@ -271,7 +285,7 @@ int csmoe_combine_bwd(const void* dout, const void* y, const int32_t* perm, cons
 
 int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
                        const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
-                       const void* aux, int64_t ldc, int epilogue, int act, int dtype, int force_generic,
+                       const void* aux, int64_t ldc, int epilogue, int act, int dtype, int kernel,
                        csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype), "grouped_gemm: bad dtype %d", dtype);
   CSMOE_CHECK_ARG(E > 0 && M >= 0 && N > 0 && Kd > 0, "grouped_gemm: bad shape E=%d M=%d N=%d Kd=%d", E, M, N, Kd);
@@ -286,12 +300,17 @@ int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, in
   CSMOE_CHECK_ARG(lda >= Kd && ldc >= N && ldb >= (b_layout == CSMOE_B_NK ? Kd : N), "grouped_gemm: leading dimension too small");
   if (M == 0) return CSMOE_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C ? C : C2)) {
-    if (use_v2_rowspace(M, N, Kd))
-      return (use_v4_rowspace(Kd) ? gg4_rowspace : gg8_rowspace)(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2,
-                                                                 aux, ldc, epilogue, act, nullptr, nullptr, st);
-    return gg_fast_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
-                            nullptr, nullptr, st);
+  CSMOE_CHECK_ARG(kernel == CSMOE_KERNEL_AUTO || kernel == CSMOE_KERNEL_GENERIC || kernel == CSMOE_KERNEL_V2 || kernel == CSMOE_KERNEL_V4,
+                  "grouped_gemm: bad kernel selector %d", kernel);
+  // ACTGRAD_ROWSCALE with a dot table (passed in the bias slot): only the tiled bf16 kernels fill it
+  const bool wants_dot = epilogue == CSMOE_EPI_ACTGRAD_ROWSCALE && bias_ptrs != nullptr;
+  if (kernel != CSMOE_KERNEL_GENERIC && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C ? C : C2))
+    return pick_rowspace(M, N, Kd, b_layout, kernel)(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
+                                           nullptr, nullptr, st);
+  if (wants_dot) {
+    csmoe_set_error("grouped_gemm: ACTGRAD_ROWSCALE was given a dot table, but this launch (dtype %d, alignment, kernel %d) runs on the "
+                    "generic kernel, which writes none (csmoe_grouped_gemm_rowdot_cols reports 0 for it)", dtype, kernel);
+    return CSMOE_ERR_UNSUPPORTED;
   }
   return gg_generic_rowspace(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act,
                              dtype, nullptr, nullptr, st);
@@ -307,7 +326,7 @@ int csmoe_grouped_gemm_rowdot_cols(int M, int N, int Kd, int64_t lda, int64_t ld
 
 int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, int64_t ldb, const void* bias, int M, int N,
                      int Kd, void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, int dtype,
-                     int force_generic, csmoe_stream_t stream) {
+                     int kernel, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && M >= 0 && N > 0 && Kd > 0, "dense_gemm: bad arguments");
   CSMOE_CHECK_ARG(M == 0 || (A && B && (C || ((epilogue == CSMOE_EPI_BIAS_ACT || epilogue == CSMOE_EPI_ROUND_BIAS32_ACT) && C2))), "dense_gemm: null pointer");
   CSMOE_CHECK_ARG(M == 0 || epilogue != CSMOE_EPI_ACTGRAD || aux, "dense_gemm: ACTGRAD epilogue needs aux");
@@ -324,15 +343,12 @@ int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, in
                       "16-byte aligned, under 2 GiB)");
       return CSMOE_ERR_UNSUPPORTED;
     }
-    return gg8_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B, bias, st);
+    return (use_v4_rowspace(Kd, b_layout, kernel) ? gg4_rowspace : gg8_rowspace)(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2,
+                                                                       aux, ldc, epilogue, act, B, bias, st);
   }
-  if (!force_generic && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C ? C : C2)) {
-    if (use_v2_rowspace(M, N, Kd))
-      return gg8_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B,
-                          bias, st);
-    return gg_fast_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B,
-                            bias, st);
-  }
+  if (kernel != CSMOE_KERNEL_GENERIC && dtype == CSMOE_BF16 && gg_fast_rowspace_ok(lda, ldb, ldc, M, N, Kd, A, C ? C : C2))
+    return pick_rowspace(M, N, Kd, b_layout, kernel)(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act, B,
+                                           bias, st);
   return gg_generic_rowspace(A, lda, nullptr, b_layout, ldb, nullptr, nullptr, 1, M, N, Kd, C, C2, aux, ldc, epilogue, act,
                              dtype, B, bias, st);
 }

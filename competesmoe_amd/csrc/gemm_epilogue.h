@@ -67,15 +67,15 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[LAY
   // rows go through in chunks of 16 per thread (one chunk for the 512-thread layout, two for the 256-thread one: a 32-row
   // straight-line body times the 12 (variant, activation) instantiations was 1.3 MB of code and minutes of compile time)
   constexpr int CH = 16, NCH = RPT / CH;
-  bf16x8 hq[CH];
-  float rs[CH];                                // EC_ACTGRAD_RS: this thread's row scales, fetched with the pre-activations
-  auto fetch_aux = [&](int h) {
+  bf16x8 hq[CH], hq_next[CH];
+  float rs[CH], rs_next[CH];                   // EC_ACTGRAD_RS: this thread's row scales, fetched with the pre-activations
+  auto fetch_aux = [&](int h, bf16x8 (&q)[CH], float (&sc)[CH]) {
     if constexpr (CLS == EC_ACTGRAD || CLS == EC_ACTGRAD_RS) {
       if (col_ok) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
           const int r = er + RSTEP * (h * CH + i);
-          if (r < rows) hq[i] = *(const bf16x8*)((const bf16*)p.aux + (int64_t)(row0 + r) * p.ldc + ncol);
+          if (r < rows) q[i] = *(const bf16x8*)((const bf16*)p.aux + (int64_t)(row0 + r) * p.ldc + ncol);
         }
       }
     }
@@ -83,11 +83,11 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[LAY
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         const int r = er + RSTEP * (h * CH + i);
-        rs[i] = r < rows ? ((const float*)p.C2)[row0 + r] : 0.f;
+        sc[i] = r < rows ? ((const float*)p.C2)[row0 + r] : 0.f;
       }
     }
   };
-  fetch_aux(0);                                // before the staging: 16 loads in flight per thread while the tile goes to LDS
+  fetch_aux(0, hq, rs);                        // before the staging: 16 loads in flight per thread while the tile goes to LDS
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if constexpr (CLS == EC_R32_ACT) {           // fp32 bias added to the ROUNDED product (cvmm + bias)
     if (p.bias && col_ok) {
@@ -133,7 +133,13 @@ __device__ __forceinline__ void epi_run(const EpiArgs& p, const f32x4 (&acc)[LAY
   if (!col_ok && dot_tab == nullptr) return;
 #pragma unroll 1
   for (int hc = 0; hc < NCH; ++hc) {
-  if (hc > 0) fetch_aux(hc);
+  if constexpr (NCH > 1) {                      // the next chunk's pre-activations travel while this chunk is processed
+    if (hc > 0) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) { hq[i] = hq_next[i]; rs[i] = rs_next[i]; }
+    }
+    if (hc + 1 < NCH) fetch_aux(hc + 1, hq_next, rs_next);
+  }
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int r = er + RSTEP * (hc * CH + i);

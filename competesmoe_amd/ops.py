@@ -465,10 +465,11 @@ def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: to
 def grouped_gemm(A: torch.Tensor, b_ptrs: torch.Tensor, b_layout: int, ldb: int, N: int, offsets: torch.Tensor, E: int,
                  bias_ptrs: Optional[torch.Tensor] = None, epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE,
                  aux: Optional[torch.Tensor] = None, want_c2: bool = False, force_generic: bool = False, want_c: bool = True,
-                 row_scale: Optional[torch.Tensor] = None, row_dot: Optional[torch.Tensor] = None):
+                 row_scale: Optional[torch.Tensor] = None, row_dot: Optional[torch.Tensor] = None, kernel: int = 0):
     """`want_c=False` (with want_c2 and EPI_BIAS_ACT): only the activated output is written and (None, C2) returned.
     `row_scale` (fp32 [M], with EPI_ACTGRAD_ROWSCALE): multiplies the rounded product row by row before the activation gradient;
-    `row_dot` (fp32 [M, rowdot_cols(...)]): receives the partial sums of product * aux (see rowdot_cols / finish_row_dot)."""
+    `row_dot` (fp32 [M, rowdot_cols(...)]): receives the partial sums of product * aux (see rowdot_cols / finish_row_dot).
+    `kernel`: CSMOE_KERNEL_* selector (0 = the library chooses, 2 / 4 = the 8-wave / one-wave-per-SIMD 256x256 kernel: tests, A/B)."""
     M, Kd = A.shape
     Cm = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c else None
     C2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c2 else None
@@ -481,7 +482,7 @@ def grouped_gemm(A: torch.Tensor, b_ptrs: torch.Tensor, b_layout: int, ldb: int,
     with _timed("grouped_gemm_" + ("nt" if b_layout == L.B_NK else "nn"), 2.0 * M * N * Kd):
         L.check(lib.csmoe_grouped_gemm(A.data_ptr(), A.stride(0), b_ptrs.data_ptr(), b_layout, ldb, _ptr(bias_ptrs),
                                        offsets.data_ptr(), E, M, N, Kd, _ptr(Cm), _ptr(C2), _ptr(aux), N, epilogue, act,
-                                       _dt(A), int(force_generic), _stream()), "grouped_gemm")
+                                       _dt(A), 1 if force_generic else int(kernel), _stream()), "grouped_gemm")
     return (Cm, C2) if want_c2 else Cm
 
 
@@ -522,13 +523,13 @@ def f32w_ok(M: int, N: int, Kd: int) -> bool:
 
 def dense_gemm(A: torch.Tensor, B: torch.Tensor, b_layout: int, bias: Optional[torch.Tensor] = None,
                epilogue: int = L.EPI_PLAIN, act: int = L.ACT_NONE, aux: Optional[torch.Tensor] = None, want_c2: bool = False,
-               force_generic: bool = False, want_c: bool = True):
+               force_generic: bool = False, want_c: bool = True, kernel: int = 0):
     M, Kd = A.shape
     N = B.shape[0] if b_layout == L.B_NK else B.shape[1]
     Cm = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c else None
     C2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if want_c2 else None
     L.check(lib.csmoe_dense_gemm(A.data_ptr(), A.stride(0), B.data_ptr(), b_layout, B.stride(0), _ptr(bias), M, N, Kd,
-                                 _ptr(Cm), _ptr(C2), _ptr(aux), N, epilogue, act, _dt(A), int(force_generic), _stream()),
+                                 _ptr(Cm), _ptr(C2), _ptr(aux), N, epilogue, act, _dt(A), 1 if force_generic else int(kernel), _stream()),
             "dense_gemm")
     return (Cm, C2) if want_c2 else Cm
 

@@ -180,11 +180,20 @@ int csmoe_combine_bwd(const void* dout, const void* y, const int32_t* perm, cons
  * B_e = b_ptrs[e] is [N,Kd] (CSMOE_B_NK) or [Kd,N] (CSMOE_B_KN) with leading dimension ldb.
  * bias_ptrs[e] -> [N] or null; C2 / aux are [M,N] with ldc.  M = offsets[E] rows in total (upper bound `M`).
  * replaces cvmm_kernel (moe_pretrain_model/layers/cvmm.py:61-168, 354-398), the per-expert nn.Linear calls of
- * compute_moe (moe_model/model/moe/moe.py:196-204) and their grad-input (cvmm.py:519-536). */
+ * compute_moe (moe_model/model/moe/moe.py:196-204) and their grad-input (cvmm.py:519-536).
+ * `kernel` (CSMOE_KERNEL_*): 0 = the library chooses (one-wave-per-SIMD 256x256 kernel for K-contiguous weights where the shape allows, else the 8-wave
+ * 256x256 kernel, the 128x128 kernel for small / narrow problems, the generic kernel for fp32 and unaligned operands); 1 forces the
+ * generic kernel; 2 / 4 ask for the 8-wave / one-wave-per-SIMD kernel where the shape allows (tests and A/B runs: every kernel is
+ * reachable through the interface, none through hidden state).  A CSMOE_EPI_ACTGRAD_ROWSCALE launch that passes a dot table and
+ * lands on a kernel that cannot fill it returns CSMOE_ERR_UNSUPPORTED instead of leaving the table unwritten. */
+#define CSMOE_KERNEL_AUTO 0
+#define CSMOE_KERNEL_GENERIC 1
+#define CSMOE_KERNEL_V2 2
+#define CSMOE_KERNEL_V4 4
 int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
                        const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd,
                        void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, int dtype,
-                       int force_generic, csmoe_stream_t stream);
+                       int kernel, csmoe_stream_t stream);
 
 /* partial sums per row written into the dot table of CSMOE_EPI_ACTGRAD_ROWSCALE for this launch shape; 0: no table (generic kernel) */
 int csmoe_grouped_gemm_rowdot_cols(int M, int N, int Kd, int64_t lda, int64_t ldb, int64_t ldc, int dtype);
@@ -193,7 +202,7 @@ int csmoe_grouped_gemm_rowdot_cols(int M, int N, int Kd, int64_t lda, int64_t ld
  * the always-on shared expert (moe_model/model/moe/shard_smoe.py:53, deepseekv3.py:44; pretrain deepseekv2.py:154-165). */
 int csmoe_dense_gemm(const void* A, int64_t lda, const void* B, int b_layout, int64_t ldb, const void* bias, int M, int N,
                      int Kd, void* C, void* C2, const void* aux, int64_t ldc, int epilogue, int act, int dtype,
-                     int force_generic, csmoe_stream_t stream);
+                     int kernel, csmoe_stream_t stream);
 
 /* Weight-gradient GEMM: for every expert e:  C_e[0:Na, 0:Nb] = sum_{m in expert e} A[m,0:Na]^T B[m,0:Nb]
  * c_ptrs[e] -> [Na, Nb] (leading dim ldc) written in `out_dtype` (CSMOE_F32 or CSMOE_BF16); empty experts get zeros.

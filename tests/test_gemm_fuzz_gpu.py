@@ -25,16 +25,22 @@ def _cases(n, seed):
         M = rng.randrange(2048, 7000)
         N = 8 * rng.randrange(32, 140)            # 256 .. 1112
         Kd = 8 * rng.randrange(16, 190)           # 128 .. 1512
-        out.append((i, E, M, N, Kd, rng.choice([0, 1]), rng.choice([0, 1, 2, 3]), rng.choice([1, 2, 3, 4])))
+        b_layout, epi, act = rng.choice([0, 1]), rng.choice([0, 1, 2, 3]), rng.choice([1, 2, 3, 4])
+        # which 256x256 kernel: 0 = the library's choice, 2 = 8 waves, 4 = one wave per SIMD (takes K = whole pairs of K-tiles: such
+        # a K is drawn for it, and for half of the automatic cases, which then land on it too)
+        kern = rng.choice([0, 0, 2, 4, 4])
+        if kern == 4 or (kern == 0 and i % 2 == 0):
+            Kd = 128 * rng.randrange(1, 13)       # 128 .. 1536
+        out.append((i, E, M, N, Kd, b_layout, epi, act, kern))
     return out
 
 
-N_ROW = int(os.environ.get("CSMOE_FUZZ_CASES", "16"))      # a one-off long sweep: CSMOE_FUZZ_CASES=300
+N_ROW = int(os.environ.get("CSMOE_FUZZ_CASES", "28"))      # a one-off long sweep: CSMOE_FUZZ_CASES=300
 N_WGRAD = int(os.environ.get("CSMOE_FUZZ_CASES", "14"))
 
 
-@pytest.mark.parametrize("i,E,M,N,Kd,b_layout,epi,act", _cases(N_ROW, 1234))
-def test_rowspace_fuzz(i, E, M, N, Kd, b_layout, epi, act):
+@pytest.mark.parametrize("i,E,M,N,Kd,b_layout,epi,act,kern", _cases(N_ROW, 1234))
+def test_rowspace_fuzz(i, E, M, N, Kd, b_layout, epi, act, kern):
     g = torch.Generator().manual_seed(1000 + i)
     off = make_groups(E, M, seed=i, empty=E > 2)
     A = torch.randn(M, Kd, generator=g).bfloat16().to(DEV)
@@ -42,7 +48,7 @@ def test_rowspace_fuzz(i, E, M, N, Kd, b_layout, epi, act):
     Bs = [(torch.randn(*shape, generator=g) / math.sqrt(Kd)).bfloat16().to(DEV) for _ in range(E)]
     bias = [(torch.randn(N, generator=g) * 0.5).bfloat16().to(DEV) for _ in range(E)]
     aux = torch.randn(M, N, generator=g).bfloat16().to(DEV)
-    kw = dict(epilogue=epi, act=act)
+    kw = dict(epilogue=epi, act=act, kernel=kern)
     if epi in (1, 2):
         kw["bias_ptrs"] = ops.ptr_array(bias, DEV)
     if epi == 2:
@@ -51,6 +57,12 @@ def test_rowspace_fuzz(i, E, M, N, Kd, b_layout, epi, act):
         kw["aux"] = aux
     res = ops.grouped_gemm(A, ops.ptr_array(Bs, DEV), b_layout, Bs[0].stride(0), N, off.to(DEV), E, **kw)
     c, c2 = res if epi == 2 else (res, None)
+    if kern == 0 and Kd % 128 == 0:
+        # the two 256x256 kernels are independent implementations of the same sums, rounded at the same points: bit-identical
+        r2 = ops.grouped_gemm(A, ops.ptr_array(Bs, DEV), b_layout, Bs[0].stride(0), N, off.to(DEV), E, **{**kw, "kernel": 2})
+        r4 = ops.grouped_gemm(A, ops.ptr_array(Bs, DEV), b_layout, Bs[0].stride(0), N, off.to(DEV), E, **{**kw, "kernel": 4})
+        for a_, b_ in zip(r2 if epi == 2 else (r2,), r4 if epi == 2 else (r4,)):
+            assert (a_.float() - b_.float()).abs().max() <= 2 ** -7 * a_.float().abs().max()
     rc, rc2 = ref_rowspace(A, Bs, b_layout, off, bias if epi in (1, 2) else None, epi, act if epi >= 2 else 0, aux if epi == 3 else None)
     tol = dict(rtol=2 ** -7, atol=2e-2)
     assert torch.allclose(c.float(), rc.float(), **tol), (i, (c.float() - rc.float()).abs().max())
