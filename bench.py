@@ -31,15 +31,17 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_FP8_PEAK_TFLOPS = 5000.0    # dense block-scaled fp8 peak, same guide
 HBM_PEAK_GBS = 8000.0
-ROUND = "r02"                    # profiles/<ROUND>/traffic.json holds the PMC pass of THIS round's kernels (see traffic_for)
+ROUND = "r03"                    # profiles/<ROUND>/traffic.json holds the PMC passes of THIS round's kernels (see traffic_for)
 
 
-GEMM_SOURCES = ("gemm_bf16_v2.hip", "gemm_bf16_v2p.hip", "gemm_tiles.h", "gemm_epilogue.h", "common.h")    # the grouped-GEMM kernels the traffic is quoted for
+# every source a grouped-GEMM launch of any workload can come from: the traffic figure is only quoted for the kernels it was measured on
+GEMM_SOURCES = ("gemm_bf16_v4.hip", "gemm_bf16_v2.hip", "gemm_bf16_v2p.hip", "gemm_bf16_v2c.hip", "gemm_fp8.hip", "gemm_tiles.h",
+                "gemm_epilogue.h", "common.h")
 
 
 def kernel_sources_hash():
-    """sha1 over the sources of the dominant (grouped GEMM) kernels: ties a committed PMC traffic figure to the kernels it was
-    measured on."""
+    """sha1 over the sources of the grouped GEMM kernels (bf16 v4 / v2 / wgrad, fp32-weight, MXFP8): ties a committed PMC traffic
+    figure to the kernels it was measured on."""
     import hashlib
     h = hashlib.sha1()
     for f in GEMM_SOURCES:
@@ -48,17 +50,30 @@ def kernel_sources_hash():
     return h.hexdigest()[:16]
 
 
-def traffic_for(kernel):
+def workload_key(config, dtype):
+    """What a traffic figure belongs to: the workload sentence of the JSON line (stack, routing, sizes, experts), the arithmetic
+    type and the parallelism.  tools/summarize_profile.py writes it from the bench line printed under rocprofv3; traffic_for
+    reads it back for the run being timed."""
+    return {"workload": config["workload"], "dtype": dtype, "parallelism": config["parallelism"],
+            "graph_replay": bool(config.get("graph_replay", False))}
+
+
+def traffic_for(kernel, config, dtype):
     """HBM-side bytes per launch of `kernel` from this round's committed rocprofv3 --pmc passes (PMC counters cannot be read from
-    inside this process), ONLY if they were collected on the kernels being timed now (matching source hash); else None."""
+    inside this process), ONLY if they were collected on this workload (workload_key) with the kernels being timed now (matching
+    source hash); else None and the reason."""
     try:
         with open(os.path.join(ROOT, "profiles", ROUND, "traffic.json")) as fh:
             d = json.load(fh)
     except (OSError, ValueError):
-        return None, None
-    if d.get("kernel_sources_sha1_16") != kernel_sources_hash():
-        return None, f"profiles/{ROUND}/traffic.json was collected on other kernel sources: not reported"
-    return d.get("bytes_per_launch", {}).get(kernel), d.get("note")
+        return None, f"no profiles/{ROUND}/traffic.json"
+    key = workload_key(config, dtype)
+    for name, w in d.get("workloads", {}).items():
+        if w.get("key") == key:
+            if w.get("kernel_sources_sha1_16") != kernel_sources_hash():
+                return None, f"profiles/{ROUND}/traffic.json[{name}] was collected on other kernel sources: not reported"
+            return w.get("bytes_per_launch", {}).get(kernel), f"profiles/{ROUND}/traffic.json[{name}]: {w.get('note', '')}"
+    return None, f"profiles/{ROUND}/traffic.json holds no PMC pass of this workload: not reported"
 
 
 def parse():
@@ -467,9 +482,8 @@ def main():
             tot_ms = sum(v["ms"] * v["calls"] for v in big.values()) / a.steps
             tot_fl = sum(v["work"] * v["calls"] for v in big.values()) / a.steps
             tot_peak_ms = sum(v["work"] * v["calls"] / (peak_of(k) * 1e12) for k, v in big.items()) / a.steps * 1e3
-            traffic, tnote = traffic_for(dom)
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": tnote,
+                    "frac": round(ach / peak, 4), "traffic": None, "traffic_note": None,
                     "all_grouped_gemm": {"ms_per_step": round(tot_ms, 3), "TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1),
                                          "frac": round(tot_peak_ms / tot_ms, 4)},
                     "hbm_kernels": {k: {"GB/s": d["GB/s"], "frac": round(d["GB/s"] / HBM_PEAK_GBS, 4)}
@@ -488,6 +502,8 @@ def main():
             "roofline": roof, "kernels": detail,
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }
+        if roof is not None:
+            roof["traffic"], roof["traffic_note"] = traffic_for(roof["kernel"], res["config"], a.dtype)
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(a)

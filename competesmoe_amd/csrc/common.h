@@ -166,55 +166,6 @@ __device__ __forceinline__ int grouped_total_tiles(const int32_t* offsets, int E
   }
   return total;
 }
-// The same tiles in two classes: every expert's FULL row tiles first (expert, column tile, row tile), then the remainder tiles
-// (expert, column tile), each class spread over the XCDs by its own xcd_remap.  Full tiles all take the same time, so the
-// workgroups of a round start and finish together and the tiles that share a weight / activation panel keep walking K in step
-// (their re-reads hit L2); remainder tiles are shorter, and mixed in between they desynchronise their neighbours -- the idea.
-// Measured (gpurun_out r2w, same box, headline launches): SLOWER than the mixed order by 3.3 / 1.3 / 2.0 / 0 % (GEMM1 / dH / GEMM2 /
-// dXs) -- rounds that start together also reach their epilogues and their cold first fetches together; kept behind
-// CSMOE_TILE_CLASSES=1 as the record of the experiment.  `id` = blockIdx.x.  Returns false past the last tile.
-__device__ __forceinline__ bool grouped_find_tile_classes(const int32_t* offsets, int E, int single_M, int BMt, int nct, int id, int lane,
-                                                          TilePos& out) {
-  // pass 1: tiles per class
-  int tot_full = 0, tot_rem = 0;
-  for (int base = 0; base < E; base += 64) {
-    const int e = base + lane;
-    int cnt = 0;
-    if (e < E) cnt = offsets ? (offsets[e + 1] - offsets[e]) : single_M;
-    int f = wave_incl_scan((cnt / BMt) * nct, lane), r = wave_incl_scan((cnt % BMt) ? nct : 0, lane);
-    tot_full += __shfl(f, 63, 64);
-    tot_rem += __shfl(r, 63, 64);
-  }
-  const bool rem_class = id >= tot_full;
-  if (rem_class && id - tot_full >= tot_rem) return false;
-  const int v = rem_class ? xcd_remap(id - tot_full, tot_rem) : xcd_remap(id, tot_full);
-  int acc = 0;
-  for (int base = 0; base < E; base += 64) {
-    const int e = base + lane;
-    int o0 = 0, o1 = 0;
-    if (e < E) { o0 = offsets ? offsets[e] : 0; o1 = offsets ? offsets[e + 1] : single_M; }
-    const int cnt = o1 - o0;
-    const int mt_e = rem_class ? ((cnt % BMt) ? 1 : 0) : cnt / BMt;        // tiles of this class per column tile
-    const int incl = wave_incl_scan(mt_e * nct, lane) + acc;
-    const unsigned long long hit = __ballot(incl > v);
-    if (hit) {
-      const int src = __ffsll((long long)hit) - 1;
-      const int excl = __shfl(incl - mt_e * nct, src, 64);
-      const int mte = __shfl(mt_e, src, 64);
-      const int local = v - excl;
-      out.e = base + src;
-      out.o0 = __shfl(o0, src, 64);
-      out.o1 = __shfl(o1, src, 64);
-      const int full_e = (out.o1 - out.o0) / BMt;
-      out.mt = rem_class ? full_e : local % mte;
-      out.nt = rem_class ? local : local / mte;
-      return true;
-    }
-    acc = __shfl(incl, 63, 64);
-  }
-  return false;
-}
-
 __device__ __forceinline__ bool grouped_find_tile(const int32_t* offsets, int E, int single_M, int BMt, int nct, int v, int lane,
                                                   TilePos& out) {
   int acc = 0;

@@ -21,9 +21,11 @@ __device__ __forceinline__ float inv_scale_of(int sbyte) {         // 2^-(sbyte 
   const int e = 254 - sbyte;                                       // biased exponent of the reciprocal
   return e <= 0 ? __uint_as_float(0x00400000u >> (-e)) : __uint_as_float((unsigned)e << 23);
 }
+// saturate to +-448 but let a NaN through (fminf / fmaxf return their non-NaN operand, which would turn NaN into -448): the
+// conversion below encodes it as the e4m3 NaN, so a NaN activation still poisons its output row as it does on the bf16 path
+__device__ __forceinline__ float sat448(float v) { return v != v ? v : fminf(fmaxf(v, -448.f), 448.f); }
 __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
-  a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
-  c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+  a = sat448(a); b = sat448(b); c = sat448(c); d = sat448(d);
   int w = 0;
   w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);

@@ -47,7 +47,7 @@ constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int CT2_LD = BN2 + 4;              // fp32 epilogue staging row stride (floats); 128 rows per pass
 constexpr int LDS2_BYTES = EPI_LDS_BYTES;   // 135,168 B: the epilogue's bf16 staging tile (>= the 8 operand images = 131,072 B)
 
-enum { SHALLOW = 0, DEEP = 1, WIDE = 2, BAL = 3, PP = 4 };
+enum { WIDE = 2, BAL = 3 };
 
 // Diagnostic build (-DCSMOE_STAMPS, tools/tile_stamps.py): every workgroup records where it ran (XCC / SE / CU) and the 100 MHz
 // s_memrealtime at entry, at the start and the end of its K-loop and at exit, into a buffer of their own (CSMOE_STAMP_FILE gets
@@ -73,14 +73,10 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   const int nct = (p.NC + BN2 - 1) / BN2;
   if (MODE == 0) {
     TilePos tp;
-    if (p.tile_classes) {                                    // CSMOE_TILE_CLASSES=1 (A/B): full tiles first, remainder tiles last (common.h)
-      if (!grouped_find_tile_classes(p.offsets, p.E, p.single_M, BM2, nct, blockIdx.x, lane, tp)) return;
-    } else {
-      const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BM2, nct, lane);
-      if ((int)blockIdx.x >= total) return;
-      const int v = xcd_remap(blockIdx.x, total);
-      if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM2, nct, v, lane, tp)) return;
-    }
+    const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BM2, nct, lane);
+    if ((int)blockIdx.x >= total) return;
+    const int v = xcd_remap(blockIdx.x, total);
+    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM2, nct, v, lane, tp)) return;
     e = tp.e;
     row0 = tp.o0 + tp.mt * BM2; rows = min(BM2, tp.o1 - row0);
     tc0 = tp.nt * BN2;
@@ -190,21 +186,10 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   __builtin_amdgcn_sched_barrier(0);                   \
   __builtin_amdgcn_s_barrier();                        \
   __builtin_amdgcn_sched_barrier(0)
-#define MFMA_QUADRANT(FC, FR, CB0, RB0)                                                                              \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                   \
-    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                                 \
-      _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                               \
-        acc[(CB0) + cb][(RB0) + rb] =                                                                                \
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(FC[cb][ks], FR[rb][ks], acc[(CB0) + cb][(RB0) + rb], 0, 0, 0)
-
   // ragged tiles: a wave whose 64-row / 32-column strips lie outside the tile skips those reads and MFMAs (it still issues
   // its share of the DMA and takes every barrier)
   const int rows_here = (MODE == 0 ? rows : min(BM2, p.NR - tr0)) - wm * 64;
   const int cols_here = min(BN2, p.NC - tc0) - wn * 32;
-  const bool act1 = rows_here > 0 && cols_here > 0;        // C_lo x R_lo
-  const bool act2 = rows_here > 0 && cols_here > 128;      // C_hi x R_lo
-  const bool act3 = rows_here > 128 && cols_here > 128;    // C_hi x R_hi
-  const bool act4 = rows_here > 128 && cols_here > 0;      // C_lo x R_hi
 
   // Tiles of at most 128 rows (the remainder tile of an expert: with ~1024 +- 32 rows per expert every other expert has one of
   // 1..60 rows) only ever use the row image RL: a K-tile is ONE phase (C_all x R_lo), three images to fetch (6 of the 8 pieces per
@@ -358,89 +343,6 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
       PHASE_SYNC_OUT();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
-  } else if constexpr (SCHED == PP) {
-    // BAL's phases (A: C_all x R_lo, B: C_all x R_hi) with ONE barrier per phase instead of two.  The two row halves do the two
-    // sections of a phase in OPPOSITE order between the same pair of barriers:
-    //     row half 0:  MFMA(q)  then  read the fragments of phase q+1 (+ its share of the DMA issue)
-    //     row half 1:  read the fragments of phase q (+ DMA issue)  then  MFMA(q)
-    // so one half's MFMAs still run beside its SIMD partner's LDS reads / DMA issue, but the switch between the sections is not a
-    // barrier any more: per-workgroup stamps put the release latency of a barrier at ~170 cycles, four of them per K-tile against
-    // 2,048 cycles of MFMA.  Row half 0 therefore reads every image one phase EARLIER than row half 1, which moves the landing
-    // deadlines up by a phase:
-    //     [CL,CH,RL](s+1) read by half 0 in B(s), by half 1 in A(s+1): landed (counted wait + barrier) by the end of A(s),
-    //                     its slot (that of K-tile s-1) is free from B(s-1) on  -> issued in B(s-1)
-    //     RH(s+1)         read by half 0 in A(s+1), by half 1 in B(s+1):  landed by the end of B(s), slot free from A(s) on
-    //                                                                     -> issued in A(s)
-    // Issue order ... [CL,CH,RL](s+1) | RH(s+1) | [CL,CH,RL](s+2) | ...: vmcnt(2) at the end of A(s) leaves RH(s+1) in flight,
-    // vmcnt(6) at the end of B(s) leaves [CL,CH,RL](s+2).  Half 0's reads are still in flight across the barrier (retired by the
-    // lgkmcnt(0) in front of its MFMAs); the slot they read is re-filled two phases later at the earliest.  The fragments are
-    // carried across the loop edge, so the reads are unconditional (a ragged tile reads rows the descriptor zero-filled).
-    const bool rlo = rows_here > 0, rhi = rows_here > 128, clo = cols_here > 0, chi = cols_here > 128;
-    bf16x8 fc[4][2], fr[4][2];
-#define PP_READ_C(tile)                                                                                               \
-    do {                                                                                                              \
-      const char* b_ = smem + ((tile) & 1) * (4 * TILE_B);                                                            \
-      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                                \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                            \
-          fc[cb][ks] = (COLK == KC) ? frag_kc(b_ + TILE_B, kc_lane, c_blk0 + cb, ks) : frag_km_raw(b_ + TILE_B, km_c[cb], ks); \
-          fc[2 + cb][ks] = (COLK == KC) ? frag_kc(b_ + 2 * TILE_B, kc_lane, c_blk0 + cb, ks) : frag_km_raw(b_ + 2 * TILE_B, km_c[cb], ks); \
-        }                                                                                                             \
-    } while (0)
-#define PP_READ_R(tile, kind)                                                                                         \
-    do {                                                                                                              \
-      const char* i_ = smem + ((tile) & 1) * (4 * TILE_B) + (kind) * TILE_B;                                          \
-      _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                                \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
-          fr[rb][ks] = (ROWK == KC) ? frag_kc(i_, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_, km_r[rb], ks);          \
-    } while (0)
-#define PP_MFMA(RB0, on)                                                                                              \
-    do {                                                                                                              \
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
-      __builtin_amdgcn_sched_barrier(0);                                                                              \
-      __builtin_amdgcn_s_setprio(1);                                                                                  \
-      if ((on) && clo) {                                                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
-          _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                            \
-            _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                          \
-              acc[cb][(RB0) + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][(RB0) + rb], 0, 0, 0); \
-      }                                                                                                               \
-      if ((on) && chi) {                                                                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
-          _Pragma("unroll") for (int cb = 2; cb < 4; ++cb)                                                            \
-            _Pragma("unroll") for (int rb = 0; rb < 4; ++rb)                                                          \
-              acc[cb][(RB0) + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][(RB0) + rb], 0, 0, 0); \
-      }                                                                                                               \
-      __builtin_amdgcn_s_setprio(0);                                                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                              \
-    } while (0)
-#define PP_END(N)                                                                                                     \
-    do {                                                                                                              \
-      __builtin_amdgcn_sched_barrier(0);                                                                              \
-      WAIT_DMA(N);                                                                                                    \
-      __builtin_amdgcn_s_barrier();                                                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                              \
-    } while (0)
-    ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(0); ISSUE_RH(0); ISSUE_CL(1); ISSUE_CH(1); ISSUE_RL(1);
-    WAIT_DMA(8);                                           // CL, CH, RL(0) landed
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (wm == 0) { PP_READ_C(0); PP_READ_R(0, 0); }   // row half 0 enters the loop with the fragments of phase A(0)
-    WAIT_DMA(6);                                           // RH(0) landed
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    for (int s = 0; s < nk; ++s) {
-      // ---- A(s)
-      if (wm == 1) { PP_READ_C(s); PP_READ_R(s, 0); ISSUE_RH(s + 1); }
-      PP_MFMA(0, rlo);
-      if (wm == 0) { PP_READ_R(s, 3); ISSUE_RH(s + 1); }
-      PP_END(2);
-      // ---- B(s)
-      if (wm == 1) { PP_READ_R(s, 3); ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2); }
-      PP_MFMA(4, rhi);
-      if (wm == 0) { PP_READ_C(s + 1); PP_READ_R(s + 1, 0); ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2); }
-      PP_END(6);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // row half 0's reads of the (zero-filled) K-tile past the end
   } else if constexpr (SCHED == WIDE) {
     // TWO phases of 32 MFMA per K-tile (half the barriers of the 4-phase loop; all 8 row blocks stay in registers):
     //     phase A: read CL, RL, RH(s)   issue CL,CH(s+1)   vmcnt(8)   MFMA C_lo x R_all
@@ -528,73 +430,6 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
       PHASE_SYNC_OUT();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
-  } else {
-  // prologue: K-tile 0 complete; SHALLOW also the column images of K-tile 1, DEEP all of K-tile 1 except RH
-  ISSUE_RL(0); ISSUE_CL(0); ISSUE_CH(0); ISSUE_RH(0);
-  if (SCHED == DEEP) { ISSUE_RL(1); ISSUE_CL(1); ISSUE_CH(1); WAIT_DMA(10); }
-  else               { ISSUE_CL(1); ISSUE_CH(1); WAIT_DMA(4); }
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int s = 0; s < nk; ++s) {
-    const char* base = smem + (s & 1) * (4 * TILE_B);
-    const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-    bf16x8 fcl[2][2], fch[2][2], fr[4][2];
-
-    // ---- phase 1: C_lo x R_lo
-    if (act1 || act4) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fcl[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
-    }
-    if (act1 || act2) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
-    }
-    if (SCHED == DEEP) { ISSUE_RH(s + 1); WAIT_DMA(10); }   // CH(s) landed
-    else               { ISSUE_RL(s + 1); }
-    PHASE_SYNC_IN();
-    if (act1) { MFMA_QUADRANT(fcl, fr, 0, 0); }
-    PHASE_SYNC_OUT();
-
-    // ---- phase 2: C_hi x R_lo
-    if (act2 || act3) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fch[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
-    }
-    if (SCHED == DEEP) { ISSUE_RL(s + 2); WAIT_DMA(10); }   // RH(s) landed
-    else               { ISSUE_RH(s + 1); }
-    PHASE_SYNC_IN();
-    if (act2) { MFMA_QUADRANT(fch, fr, 2, 0); }
-    PHASE_SYNC_OUT();
-
-    // ---- phase 3: C_hi x R_hi
-    if (act3 || act4) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
-    }
-    ISSUE_CL(s + 2);
-    PHASE_SYNC_IN();
-    if (act3) { MFMA_QUADRANT(fch, fr, 2, 4); }
-    PHASE_SYNC_OUT();
-
-    // ---- phase 4: C_lo x R_hi.  After this phase's wait + barrier A every image of K-tile s+1 that phase 1 reads has landed.
-    ISSUE_CH(s + 2);
-    if (SCHED == DEEP) { WAIT_DMA(10); } else { WAIT_DMA(4); }
-    PHASE_SYNC_IN();
-    if (act4) { MFMA_QUADRANT(fcl, fr, 0, 4); }
-    PHASE_SYNC_OUT();
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
-
   }
 
   RT_STAMP(st_loop_end);
@@ -665,17 +500,18 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
 #endif
 }
 
-// CSMOE_GEMM_SCHED=1|2|3|4 forces DEEP / WIDE / BAL / PP for every row-space launch (A/B runs); unset = the measured best per
-// layout: BAL for NT (both operands K-contiguous: +4 % over WIDE), WIDE for NN (K-major weights: BAL is 1-4 % slower there).
-// PP (one barrier per phase) is bit-identical and 2-4 % SLOWER than either on all four headline launches (gpurun_out r2r): the
-// barriers are not what the loop waits for -- see the stamp results in DESIGN.md section 3.
+// CSMOE_GEMM_SCHED=2|3 forces WIDE / BAL for every row-space launch (A/B runs); unset = the measured best per layout: BAL for NT
+// (both operands K-contiguous: +4 % over WIDE), WIDE for NN (K-major weights: BAL is 1-4 % slower there).  Round 3 removed the loops
+// that had lost every comparison and were no longer instantiated by default -- the four-phase SHALLOW / DEEP loops (rounds 1-2:
+// 6-16 % slower than WIDE), PP (one barrier per phase: 2-4 % slower, gpurun_out r2r), the class-sorted tile order
+// (CSMOE_TILE_CLASSES: 0-3 % slower) -- they are in the history (commit 1d8bf29), their measurements in DESIGN.md section 3.
 int sched_pref(int b_layout) {
   static int v = -2;
   if (v == -2) {
     const char* e = getenv("CSMOE_GEMM_SCHED");
     v = e ? atoi(e) : -1;
   }
-  if (v >= 0) return v;
+  if (v == WIDE || v == BAL) return v;
   return b_layout == CSMOE_B_NK ? BAL : WIDE;
 }
 
@@ -703,8 +539,6 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
   {
     static const int thin = [] { const char* e = getenv("CSMOE_THIN_LOOP"); return e ? atoi(e) : 1; }();
     p.thin_loop = thin;
-    static const int classes = [] { const char* e = getenv("CSMOE_TILE_CLASSES"); return e ? atoi(e) : 0; }();
-    p.tile_classes = classes;
   }
   int nct = (N + BN2 - 1) / BN2;
   int64_t grid = (int64_t)nct * ((M + BM2 - 1) / BM2 + E);
@@ -712,7 +546,6 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_gemm: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;
   const int sp = sched_pref(b_layout);
-  const bool wide = sp == WIDE;
 #ifdef CSMOE_STAMPS
   struct StampDump {
     unsigned long long* buf; int64_t n; hipStream_t st;
@@ -741,28 +574,8 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
       if ((rc = set_lds2(gg8_kernel<KC, KM, 0, S>))) return rc;                                                       \
       hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, S>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);             \
     }                                                                                                                 \
-    CSMOE_CHECK_LAUNCH("grouped_gemm(bf16 v2)");                                                                      \
-    return CSMOE_OK;                                                                                                  \
   } while (0)
-  if (sp == PP) LAUNCH_SCHED(PP);
-  if (sp == BAL) LAUNCH_SCHED(BAL);
-  if (b_layout == CSMOE_B_NK) {
-    if (wide) {
-      if ((rc = set_lds2(gg8_kernel<KC, KC, 0, WIDE>))) return rc;
-      hipLaunchKernelGGL((gg8_kernel<KC, KC, 0, WIDE>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
-    } else {
-      if ((rc = set_lds2(gg8_kernel<KC, KC, 0, DEEP>))) return rc;
-      hipLaunchKernelGGL((gg8_kernel<KC, KC, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
-    }
-  } else {
-    if (wide) {
-      if ((rc = set_lds2(gg8_kernel<KC, KM, 0, WIDE>))) return rc;
-      hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, WIDE>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
-    } else {
-      if ((rc = set_lds2(gg8_kernel<KC, KM, 0, DEEP>))) return rc;
-      hipLaunchKernelGGL((gg8_kernel<KC, KM, 0, DEEP>), dim3((unsigned)grid), dim3(512), LDS2_BYTES, st, p);
-    }
-  }
+  if (sp == BAL) LAUNCH_SCHED(BAL); else LAUNCH_SCHED(WIDE);
   CSMOE_CHECK_LAUNCH("grouped_gemm(bf16 v2)");
   return CSMOE_OK;
 }

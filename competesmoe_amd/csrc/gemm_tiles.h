@@ -29,7 +29,6 @@ struct FastArgs {
   int epilogue, act, accumulate, out_f32;
   const int32_t* xcd_order;                   // persistent wgrad: experts dealt to XCDs (csmoe_expert_order), or null
   int thin_loop;                              // row-space v2: tiles of <= 128 rows take the one-phase loop
-  int tile_classes;                           // row-space v2: full tiles first, remainder tiles last (grouped_find_tile_classes)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {

@@ -437,11 +437,14 @@ def pretrain_diversity_loss(topk_out: torch.Tensor, op_dtype=None) -> torch.Tens
     return sim.mean()
 
 
-def pretrain_deepseek_forward(x, w_gate, keys, values, keys_shared, values_shared, k, mode: str, op_dtype, x_dtype, forced_idx=None):
+def pretrain_deepseek_forward(x, w_gate, keys, values, keys_shared, values_shared, k, mode: str, op_dtype, x_dtype, forced_idx=None,
+                              ffn=None):
     """DeepSeekV2.forward (moe_pretrain_model/layers/moe/deepseekv2.py:135-181: top-k of the logits, softmax over the K)
     and DeepSeekV3.forward (deepseekv3.py:142-190: top-k of sigmoid(logits), w / (sum + 1e-20)), both plus the always-on shared
     expert (a 1-expert cvmm with an all-zero selection and unit weight = a dense FFN).  Returns (out, gate_logits).
-    `forced_idx`: evaluate with given (tie-broken) indices -- the reference's own, or the kernel's -- instead of the lowest-index rule."""
+    `forced_idx`: evaluate with given (tie-broken) indices -- the reference's own, or the kernel's -- instead of the lowest-index rule.
+    `ffn`: what computes the experts (default pretrain_ffn, the reference's two cvmm calls; oracle/mxfp8.py's for the fp8 build)."""
+    ffn = ffn or pretrain_ffn
     B, N, D = x.shape
     xx = x.to(op_dtype)
     lg = F.linear(xx, w_gate.to(op_dtype))
@@ -454,10 +457,10 @@ def pretrain_deepseek_forward(x, w_gate, keys, values, keys_shared, values_share
         idx = topk_lowest_index(sg.detach().float(), k)[1] if forced_idx is None else forced_idx
         w = torch.gather(sg, -1, idx)
         w = w / (w.float().sum(dim=-1, keepdim=True) + 1e-20)
-    out = pretrain_ffn(x, idx, w, keys, values, "relu", op_dtype)
+    out = ffn(x, idx, w, keys, values, "relu", op_dtype)
     zero = torch.zeros(B, N, 1, dtype=torch.long)
     one = torch.ones(B, N, 1)
-    shared = pretrain_ffn(x, zero, one, keys_shared, values_shared, "relu", op_dtype)
+    shared = ffn(x, zero, one, keys_shared, values_shared, "relu", op_dtype)
     return out + shared, lg
 
 

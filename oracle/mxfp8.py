@@ -46,3 +46,127 @@ def grouped_matmul(Aq, As, Bq, Bs, offsets) -> torch.Tensor:
         if r1 > r0:
             out[r0:r1] = A[r0:r1] @ dequantize(Bq[e], Bs[e]).t()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- the FFN on MXFP8
+# Restatement of what competesmoe_amd.functional.MoEFFNPackedFP8 / DenseFFNFP8 DEFINE (there is no upstream fp8 FFN to follow; the
+# surrounding layer is deepseekv2.py:97-181 of the pretrain stack, restated in oracle/moe_oracle.py): every row-space product takes
+# both operands MX-quantised along its reduction dim, accumulates in fp32 and returns bf16; the weight gradients are bf16 products.
+_ACT = {"relu": (torch.relu, lambda h: (h > 0).double()),
+        "gelu": (torch.nn.functional.gelu,
+                 lambda h: 0.5 * (1 + torch.erf(h.double() / 2 ** 0.5)) + h.double() * torch.exp(-0.5 * h.double() ** 2) / (2 * torch.pi) ** 0.5)}
+
+
+# ReLU makes the comparison with a kernel ill-conditioned wherever a pre-activation is within the kernel's accumulation error of zero:
+# either side of the mask is a correct result there, and ONE flipped entry moves a small test's dH / dX / dW1 by 1e-3..1e-2 relative
+# L2.  The block-scaled MFMA does not carry fp32 through its 128-term sums: measured on MI355X (tools/fp8_dense_probe.py), a K = 256
+# product of O(1) x O(0.06) terms is off by up to 4e-5 absolute (about 2^-15 of the sum of magnitudes), and the mask entries that
+# differed from this oracle's had |h| = 8e-6 and 3.5e-5.  The oracle therefore reports every pre-activation within NEAR_ZERO of zero
+# ("near": expert -> (token ids, hidden ids)); tests compare the entries such a flip reaches (that token's dx row, that column of the
+# expert's key gradient and bias gradient) with a loose bound and everything else with the tight one.
+NEAR_ZERO = 1e-4
+RECORDED = []          # one {expert: (token ids, hidden ids)} per _MXFFNFn.forward, in call order (layer-level tests)
+
+
+def _mx(v: torch.Tensor) -> torch.Tensor:
+    """quantise along the last dim and dequantise: the values the matrix pipe multiplies (fp64)."""
+    return dequantize(*quantize(v.float()))
+
+
+def _bf(v: torch.Tensor) -> torch.Tensor:
+    return v.float().bfloat16()
+
+
+def ffn_forward_backward(x2, idx, w, keys, values, act: str, dout, bias=None):
+    """Routed experts.  x2 [T, D] bf16, idx [T, K], w [T, K] fp32, keys [E, D, F], values [E, F, Dout] (masters, any float dtype),
+    dout [T, Dout] bf16 -> dict(out, dx, dw, gk, gv[, gb]).  Per (token, k) slot of expert e (the order of an expert's rows does not
+    enter: every row is its own product, and the weight-gradient sums are taken in fp64 here):
+      h = bf16(mx_D(x) . mx_D(keys[e]) + bias[e]);  a = bf16(act(h));  y = bf16(mx_F(a) . mx_F(values[e]))
+      out[t] = bf16(sum_k bf16(w)[t,k] y[t,k]);  dy = bf16(bf16(w) dout);  dw[t,k] = y[t,k] . dout[t]
+      dh = bf16(bf16(mx_Dout(dy) . mx_Dout(values[e])) act'(h));  gv[e] = a^T dy;  gk[e] = x^T dh   (bf16 operands, fp32 sums)
+      dxs = bf16(mx_F(dh) . mx_F(keys[e]));  dx[t] = bf16(sum_k dxs[t,k])"""
+    f, fgrad = _ACT[act]
+    T, D = x2.shape
+    K = idx.shape[-1]
+    E, _, Fh = keys.shape
+    wb = _bf(w).double()
+    kf, vf = keys.float(), values.float()
+    k_fwd = _mx(kf.transpose(1, 2))            # [E, F, D], blocks along D
+    k_bwd = _mx(kf)                            # [E, D, F], blocks along F
+    v_fwd = _mx(vf.transpose(1, 2))            # [E, Dout, F], blocks along F
+    v_bwd = _mx(vf)                            # [E, F, Dout], blocks along Dout
+    xq = _mx(x2)
+    out = torch.zeros(T, values.shape[-1], dtype=torch.float64)
+    y_all = torch.zeros(T, K, values.shape[-1], dtype=torch.float64)
+    dx = torch.zeros(T, D, dtype=torch.float64)
+    gk = torch.zeros(E, D, Fh, dtype=torch.float64)
+    gv = torch.zeros(E, Fh, values.shape[-1], dtype=torch.float64)
+    gb = None if bias is None else torch.zeros(E, Fh, dtype=torch.float64)
+    saved, near = {}, {}
+    for e in range(E):
+        t, k = (idx == e).nonzero(as_tuple=True)
+        if t.numel() == 0:
+            continue
+        h = xq[t] @ k_fwd[e].t()
+        if bias is not None:
+            h = h + _bf(bias[e]).double()
+        nz = (h.abs() < NEAR_ZERO).nonzero(as_tuple=True)
+        if nz[0].numel():
+            near[e] = (t[nz[0]], nz[1])
+        h = _bf(h)
+        a = _bf(f(h.float()))
+        y = _bf(_mx(a) @ v_fwd[e].t()).double()
+        y_all[t, k] = y
+        saved[e] = (t, k, h, a)
+    out = _bf((wb.unsqueeze(-1) * y_all).sum(1))
+    dw = (y_all * dout.double().unsqueeze(1)).sum(-1)
+    for e, (t, k, h, a) in saved.items():
+        dy = _bf(wb[t, k].unsqueeze(-1) * dout[t].double())
+        dh = _bf(_bf(_mx(dy) @ v_bwd[e].t()).double() * fgrad(h))
+        gv[e] = a.double().t() @ dy.double()
+        gk[e] = x2[t].double().t() @ dh.double()
+        if gb is not None:
+            gb[e] = dh.double().sum(0)
+        dx.index_put_((t,), _bf(_mx(dh) @ k_bwd[e].t()).double(), accumulate=True)
+    res = {"out": out, "dx": _bf(dx), "dw": dw, "gk": gk, "gv": gv, "near": near}
+    if gb is not None:
+        res["gb"] = gb
+    return res
+
+
+def dense_ffn_forward_backward(x2, w1, w2, act: str, dout, b1=None):
+    """The always-on shared expert (DenseFFNFP8): the routed form with one expert, K = 1 and unit weight, no combine rounding."""
+    T = x2.shape[0]
+    r = ffn_forward_backward(x2, torch.zeros(T, 1, dtype=torch.long), torch.ones(T, 1), w1[None], w2[None], act, dout,
+                             None if b1 is None else b1[None])
+    out = {"out": r["out"], "dx": r["dx"], "gw1": r["gk"][0], "gw2": r["gv"][0], "near": r["near"]}
+    if b1 is not None:
+        out["gb1"] = r["gb"][0]
+    return out
+
+
+class _MXFFNFn(torch.autograd.Function):
+    """ffn_forward_backward as an autograd node, so that the MX FFN can stand where oracle/moe_oracle.py's pretrain_ffn stands in a
+    layer (the routing weights' gradient then flows on into the gate as it does there)."""
+
+    @staticmethod
+    def forward(ctx, x2, idx, w, keys, values, act):
+        ctx.save_for_backward(x2, idx, w, keys, values)
+        ctx.act = act
+        r = ffn_forward_backward(x2, idx, w, keys, values, act, torch.zeros(x2.shape[0], values.shape[-1]).bfloat16())
+        RECORDED.append(r["near"])
+        return r["out"]
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, idx, w, keys, values = ctx.saved_tensors
+        r = ffn_forward_backward(x2, idx, w, keys, values, ctx.act, _bf(dout))
+        return r["dx"].to(x2.dtype), None, r["dw"].to(w.dtype), r["gk"].to(keys.dtype), r["gv"].to(values.dtype), None
+
+
+def pretrain_ffn(x, idx, weights, keys, values, act, op_dtype, bias=None, o_bias=None):
+    """Drop-in for oracle/moe_oracle.py pretrain_ffn (same arguments) with the two grouped products on MXFP8."""
+    assert op_dtype == torch.bfloat16 and bias is None and o_bias is None
+    B, N, D = x.shape
+    out = _MXFFNFn.apply(x.reshape(B * N, D).to(op_dtype), idx.reshape(B * N, -1), weights.reshape(B * N, -1).float(), keys, values, act)
+    return out.view(B, N, -1)

@@ -44,3 +44,42 @@ def test_zero_blocks_and_grouped_matmul():
     out = MX.grouped_matmul(Aq, As, Bq, Bs, off)
     ref = torch.cat([A[:4] @ B[0].t(), A[4:] @ B[1].t()])
     assert float((out - ref.double()).norm() / ref.double().norm()) <= 5e-2
+
+
+def test_mx_ffn_tracks_the_exact_ffn_within_the_format_error_and_is_exact_on_exact_data():
+    """ffn_forward_backward (what tests/test_fp8_gpu.py checks the fp8 layer against): on random data every output and gradient is
+    within the format's error of the fp64 FFN (3.6 % per quantised operand); on data every quantiser represents
+    exactly (small integers, ReLU) it IS the fp64 FFN."""
+    torch.manual_seed(0)
+    T, D, Fh, E, K = 64, 64, 96, 4, 2
+    idx = torch.stack([torch.randperm(E)[:K] for _ in range(T)])
+
+    def exact(x, w, keys, values, dout, act):
+        xd, kd, vd = x.double().requires_grad_(True), keys.double().requires_grad_(True), values.double().requires_grad_(True)
+        wd = w.bfloat16().double().requires_grad_(True)
+        out = torch.zeros(T, D, dtype=torch.float64)
+        for k in range(K):
+            for e in range(E):
+                m = (idx[:, k] == e).nonzero().squeeze(-1)
+                if m.numel():
+                    out = out.index_add(0, m, wd[m, k].unsqueeze(-1) * (act(xd[m] @ kd[e]) @ vd[e]))
+        out.backward(dout.double())
+        return {"out": out.detach(), "dx": xd.grad, "dw": wd.grad, "gk": kd.grad, "gv": vd.grad}
+
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    x, w, dout = torch.randn(T, D).bfloat16(), torch.rand(T, K), torch.randn(T, D).bfloat16()
+    keys, values = torch.randn(E, D, Fh) * 0.1, torch.randn(E, Fh, D) * 0.1
+    r = MX.ffn_forward_backward(x, idx, w, keys, values, "gelu", dout)
+    ex = exact(x, w, keys, values, dout, torch.nn.functional.gelu)
+    for k in ex:
+        assert 1e-3 < rel(r[k], ex[k]) <= 0.1, (k, rel(r[k], ex[k]))
+    xi = torch.randint(-2, 3, (T, D)).float().bfloat16()
+    ki, vi = torch.randint(-1, 2, (E, D, Fh)).float(), torch.randint(-1, 2, (E, Fh, D)).float()
+    ki[:, :, ::2], vi[:, ::3] = 0, 0                       # keeps |h|, |y| <= 256: every intermediate is a bf16 AND an e4m3-block value
+    xi[:, 8:], vi[:, 40:] = 0, 0
+    wi, di = torch.ones(T, K), torch.randint(-1, 2, (T, D)).float().bfloat16()
+    r = MX.ffn_forward_backward(xi, idx, wi, ki, vi, "relu", di)
+    ex = exact(xi, wi, ki, vi, di, torch.relu)
+    assert float(ex["out"].abs().max()) > 0
+    for k in ("out", "dw", "gv"):
+        assert rel(r[k], ex[k]) == 0.0, (k, rel(r[k], ex[k]))

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Evidence for profiles/: one kernel-trace run and three SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE, MFMA busy) of the same
-# bench command, then the per-launch summary.  usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>
+# bench command, then the per-launch summary and this workload's entry of gpurun_out/<tag>/traffic.json (copy both into profiles/rNN/
+# TOGETHER: bench.py reads roofline.traffic from there).  usage (on the GPU box, from the repo root): tools/profile_round.sh <tag> [bench flags]
 set -u
 TAG=${1:-v6}
 shift
@@ -20,7 +21,8 @@ find $OUT -name "*.csv" | head -20
 python3 tools/summarize_profile.py $(find $OUT/kt -name "*kernel_trace.csv") $OUT/bench_${TAG}_per_launch.txt \
   --fetch $(find $OUT/pf -name "*counter_collection.csv") --write $(find $OUT/pw -name "*counter_collection.csv") \
   --mfma $(find $OUT/pm -name "*counter_collection.csv") \
-  --title "round ${ROUND:-2}, build $TAG: rocprofv3 of \`python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA\` on MI355X" > /dev/null
+  --traffic-json $OUT/traffic.json --workload $TAG --bench-json $OUT/bench_${TAG}_under_rocprof.json \
+  --title "round ${ROUND:-3}, build $TAG: rocprofv3 of \`python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA\` on MI355X" > /dev/null
 cp $(find $OUT/kt -name "*kernel_stats.csv") $OUT/bench_${TAG}_kernel_stats.csv
 # the counter CSVs are large: keep the summaries only
 rm -rf $OUT/pf $OUT/pw $OUT/pm $OUT/kt/*/*kernel_trace.csv 2>/dev/null

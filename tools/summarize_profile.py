@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 CSVs (kernel trace + separate --pmc passes) into the per-launch summary kept under profiles/.
-usage: summarize_profile.py <kernel_trace.csv> <out.txt> [--fetch f.csv] [--write w.csv] [--mfma m.csv] [--title ...]"""
+usage: summarize_profile.py <kernel_trace.csv> <out.txt> [--fetch f.csv] [--write w.csv] [--mfma m.csv] [--title ...]
+                            [--traffic-json profiles/rNN/traffic.json --workload NAME --bench-json <bench line printed under rocprofv3>]
+With --traffic-json the measured FETCH_SIZE + WRITE_SIZE bytes per launch of the grouped-GEMM kernels are merged into that file
+under NAME, keyed by bench.workload_key() of the bench line and the hash of the kernel sources, which is what bench.py's
+roofline.traffic reads back."""
 import argparse
 import collections
 import csv
+import json
+import os
 import re
+import sys
 
 
 def short(n):
-    m = re.search(r'(gg8_kernel<[^>]*>|gg_fast_kernel<[^>]*>|gg_generic_kernel<[^>]*>)', n)
+    m = re.search(r'(gg[48]_kernel<[^>]*>|gg_fast_kernel<[^>]*>|gg_generic_kernel<[^>]*>)', n)
     if m:
         return m.group(1)
     m = re.search(r'N12_GLOBAL__N_1\d+([a-z_0-9]+kernel)', n)
@@ -28,6 +35,15 @@ def pmc(path, name):
     return {k: sum(v) / len(v) for k, v in a.items()}
 
 
+def bench_name(k):
+    """bench.py's profile label (ops._timed) of a grouped-GEMM kernel: operand layout for the bf16 kernels, the file for the others."""
+    if re.match(r'gg4_kernel<0>|gg8_kernel<0, 0,', k):
+        return "grouped_gemm_nt"
+    if re.match(r'gg4_kernel<1>|gg8_kernel<0, 1,', k) or k == "gg8c_kernel":      # gg8c: fp32 master weights, K-major (ops.grouped_gemm_f32w)
+        return "grouped_gemm_nn"
+    return {"gg8w_kernel": "grouped_wgrad_tn", "gg8f_kernel": "grouped_gemm_mxfp8"}.get(k)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
@@ -36,6 +52,9 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--mfma")
     ap.add_argument("--title", default="")
+    ap.add_argument("--traffic-json")
+    ap.add_argument("--workload")
+    ap.add_argument("--bench-json")
     a = ap.parse_args()
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(a.trace)):
@@ -64,6 +83,36 @@ def main():
             fo.write(f"{k:30s} {gs:>10s} {len(v):5d} {avg:8.3f} {fk if fk is not None else float('nan'):11.0f} "
                      f"{wk if wk is not None else float('nan'):11.0f} {g1:8.3f} {g2:9.3f} {util:9.3f} {clk:8.2f}\n")
     print(open(a.out).read())
+    if a.traffic_json:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        import bench
+        line = [l for l in open(a.bench_json) if l.startswith("{")][-1]
+        res = json.loads(line)
+        tot = collections.defaultdict(lambda: [0.0, 0])
+        for (k, gs), v in d.items():
+            name, fk, wk = bench_name(k), f.get((k, gs)), w.get((k, gs))
+            if name and fk is not None and wk is not None and sum(v) / len(v) > 0.5:      # the big launches only (not the gate-sized ones)
+                tot[name][0] += (fk + wk) * 1024 * len(v)
+                tot[name][1] += len(v)
+        try:
+            cur = json.load(open(a.traffic_json))
+        except (OSError, ValueError):
+            cur = {}
+        cur["_comment"] = ("HBM/fabric-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, KiB -> bytes; Infinity-Cache "
+                           "hits included; for the GEMMs' LDS-DMA reads FETCH_SIZE is taken un-doubled -- TCC_MISS * 128 B matched it in round 1's "
+                           "calibration), call-weighted mean over the launches bench.py times under one label.  Written by tools/summarize_profile.py "
+                           "from the per-launch table named in each entry; bench.py quotes an entry only for the workload and kernel sources it was "
+                           "measured on.")
+        cur.setdefault("workloads", {})[a.workload] = {
+            "key": bench.workload_key(res["config"], res["dtype"]),
+            "kernel_sources_sha1_16": bench.kernel_sources_hash(),
+            "note": f"FETCH_SIZE + WRITE_SIZE per launch from {os.path.basename(a.out)}",
+            "bytes_per_launch": {k: int(round(b / n)) for k, (b, n) in sorted(tot.items())},
+        }
+        with open(a.traffic_json, "w") as fo:
+            json.dump(cur, fo, indent=1)
+            fo.write("\n")
 
 
 if __name__ == "__main__":
