@@ -90,6 +90,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
                     help="fp8: BASELINE config 5 -- the pretrain stack's deepseekv2 layer (routed experts + --shared shared experts) with "
                          "GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 matrix pipe (fp32 master weights quantised directly, bf16 autocast)")
+    ap.add_argument("--fp8-weight-cache", action="store_true",
+                    help="--dtype fp8: keep the quantised expert weights while the parameters are unchanged (args.fp8_weight_cache; the timed "
+                         "steps then model the micro-batches after the first of a gradient-accumulation step).  Off by default: every step quantises")
     ap.add_argument("--shared", type=int, default=0, help="number of shared experts (width n x d_ff) of the deepseekv2 layer (fp8 / --stack pretrain)")
     ap.add_argument("--skew", action="store_true", help="add +2.0 to 8 gate rows (Zipf-like load, BASELINE.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,6 +154,7 @@ def make_pretrain_layer(a, dev):
     if a.dtype == "fp8" or a.shared > 0:
         name = "deepseekv2" if a.shared > 0 else "smoe"
         args.fp8_experts = a.dtype == "fp8"
+        args.fp8_weight_cache = bool(a.fp8_weight_cache)
         args.n_shared_experts = max(1, a.shared)
     with torch.device(dev):
         layer = get_moe(name)(a.d_model, a.experts, a.d_ff, n_heads=a.topk, activation=F.relu, bias=False, log_interval=None,
@@ -459,7 +463,7 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel family (grouped expert GEMM): FLOPs per launch / mean launch duration
-        gemm = {k: v for k, v in prof.items() if k.startswith("grouped_gemm") or k.startswith("grouped_wgrad") or k == "gate_wgrad"
+        gemm = {k: v for k, v in prof.items() if k.startswith("grouped_gemm") or k.startswith("grouped_wgrad") or k.startswith("dense_wgrad") or k == "gate_wgrad"
                 or k.startswith("dense_gemm_mxfp8")}
         detail = {}
         for k, v in prof.items():
@@ -492,7 +496,7 @@ def main():
             "metric": f"MoE-layer fwd+bwd tokens/sec at d_model={D}, {a.experts} experts top-{a.topk}", "value": round(total_tokens * a.steps / el, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": ((f"BASELINE config 5: pretrain-stack deepseekv2 layer, {a.experts} routed + {a.shared} shared experts, GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 matrix pipe (fp32 master weights quantised directly, bf16 weight gradients): " if a.dtype == "fp8" else "pretrain-stack layer (packed fp32 master weights, ReLU, no bias, bf16 autocast; weights cast to bf16 every step): ") if a.stack == "pretrain" else "") + ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
+            "config": {"workload": ((f"BASELINE config 5: pretrain-stack deepseekv2 layer, {a.experts} routed + {a.shared} shared experts, GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 matrix pipe (fp32 master weights quantised directly, bf16 weight gradients" + ("; quantised weights reused while the parameters are unchanged, as over the micro-batches of one optimizer step" if a.fp8_weight_cache else "; weights quantised every step") + "): " if a.dtype == "fp8" else "pretrain-stack layer (packed fp32 master weights, ReLU, no bias, bf16 autocast; weights cast to bf16 every step): ") if a.stack == "pretrain" else "") + ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
                                    f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, " + ("ReLU experts without bias, " if a.stack == "pretrain" else "Linear+bias/GELU experts, ") +
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
                        "graph_replay": bool(a.graph), "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,

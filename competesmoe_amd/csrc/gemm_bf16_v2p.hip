@@ -30,6 +30,9 @@ using namespace ggt;
 
 namespace {
 
+#ifndef CSMOE_WG_VARIANT
+#define CSMOE_WG_VARIANT 0
+#endif
 constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
 constexpr int CT2_LD = BN2 + 4;                       // fp32 staging row stride (floats)
 constexpr int STG_OFF = 4 * TILE_B;                   // staging tile = upper half (the parity-1 slots)
@@ -462,6 +465,35 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
           *(f32x4*)(stg + m * CT2_LD + n) = acc[cb][4 * h + 2 * u + i];
         }
       EPI_SYNC();
+      if (p.out_f32) {
+        // fp32 output (the pretrain stack's master-weight gradients): one store instruction = ONE 1-KiB row segment (64 lanes x 16 B,
+        // eight full 128-B lines) instead of two rows half-written per instruction (lanes 32 B apart, the other halves in the next
+        // instruction): -4..7 % per launch at 128 experts x 512 rows, -3.5 % at 64 x 1024 (tools/wgrad_ab.sh, round 3)
+        const int ec4 = (tid_e & 63) * 4, er8 = tid_e >> 6;
+        const int ncol4 = cur.tc0 + ec4;
+        f32x4 rw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rw[j] = *(const f32x4*)(stg + (er8 + 8 * j) * CT2_LD + ec4);
+        if (pass == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ncol4 < p.NC) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = er8 + 8 * j;
+            const int trow = h * 128 + (r >> 5) * 64 + u * 32 + (r & 31);
+            if (trow < nrows) {
+              typedef __attribute__((address_space(1))) f32x4 gf32x4;
+              gf32x4* dst = (gf32x4*)(Ce + ((int64_t)(cur.tr0 + trow) * p.ldc + ncol4) * 4);
+              f32x4 a = rw[j];
+              if (p.accumulate) a += dst[0];
+#if CSMOE_WG_VARIANT == 2                 // timing experiment: no global stores at all (results are wrong): what the stores cost
+              if (a[0] == 1.2345e30f) dst[0] = a;
+#else
+              dst[0] = a;
+#endif
+            }
+          }
+        }
+      } else {
       f32x4 lo[4], hi[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -503,6 +535,7 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
             }
           }
         }
+      }
       }
       EPI_SYNC();
       STAMP(5 + pass);

@@ -138,6 +138,60 @@ __global__ void __launch_bounds__(512, 2) gg8f_kernel(Fp8Args p) {
   const int cols_here = ncols - wn * 32;
   const bool rlo = rows_here > 0, rhi = rows_here > 128, clo = cols_here > 0, chi = cols_here > 128;
 
+  if (rows <= 128) {
+    // Thin tile (the remainder tile of an expert: at 128 experts x ~512 rows half of the experts end in one of a few dozen rows):
+    // the one-phase loop of gemm_bf16_v2.hip -- no RH image, one barrier pair and 7 pieces per K-tile, every wave's 4 x 4 blocks
+    // of C_all x R_lo in one MFMA section.
+    ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(0); ISSUE_SC(0); ISSUE_CL(1); ISSUE_CH(1); ISSUE_RL(1); ISSUE_SC(1);
+    WAIT_DMA(7);                                           // K-tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < nk; ++s) {
+      const char* base = smem + (s & 1) * (4 * TILE_B);
+      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B;
+      const char* sc = SCSLOT(s);
+      i32x8 fc[4], fr[4];
+      int sc_c[4], sc_r[4];
+      if (rlo && clo) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          fc[cb] = FRAG(i_cl, c_blk0 + cb);
+          sc_c[cb] = *(const uint8_t*)(sc + 1024 + ((c_blk0 + cb) * 16 + i16) * 4 + g);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          fr[rb] = FRAG(i_rl, r_blk0 + rb);
+          sc_r[rb] = *(const uint8_t*)(sc + ((r_blk0 + rb) * 16 + i16) * 4 + g);
+        }
+      }
+      if (rlo && chi) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          fc[2 + cb] = FRAG(i_ch, c_blk0 + cb);
+          sc_c[2 + cb] = *(const uint8_t*)(sc + 1024 + (128 + (c_blk0 + cb) * 16 + i16) * 4 + g);
+        }
+      }
+      PHASE_SYNC_IN();                                     // every wave's reads of this slot are retired: it may be re-filled
+      __builtin_amdgcn_s_setprio(0);
+      ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2); ISSUE_SC(s + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (rlo && clo) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) MFMA8(acc[cb][rb], fc[cb], fr[rb], sc_c[cb], sc_r[rb]);
+      }
+      if (rlo && chi) {
+#pragma unroll
+        for (int cb = 2; cb < 4; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) MFMA8(acc[cb][rb], fc[cb], fr[rb], sc_c[cb], sc_r[rb]);
+      }
+      WAIT_DMA(7);                                         // K-tile s+1 landed (s+2 stays in flight)
+      PHASE_SYNC_OUT();
+    }
+  } else {
   // issue order ... [CL,CH,RL,SC](s+1) | RH(s+1) | [CL,CH,RL,SC](s+2) | RH(s+2) ...: 7 + 2 pieces per K-tile and wave, so the
   // counted waits of the bf16 loop (8) become 9
   ISSUE_CL(0); ISSUE_CH(0); ISSUE_RL(0); ISSUE_SC(0); ISSUE_RH(0); ISSUE_CL(1); ISSUE_CH(1); ISSUE_RL(1); ISSUE_SC(1);
@@ -216,6 +270,7 @@ __global__ void __launch_bounds__(512, 2) gg8f_kernel(Fp8Args p) {
     PHASE_SYNC_OUT();
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
+  }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();

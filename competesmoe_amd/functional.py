@@ -1004,15 +1004,45 @@ class DiversityLoss(torch.autograd.Function):
 
 
 # ======================================================================================================== MXFP8 experts
+# Quantised master weights, kept while the parameter is unchanged (`args.fp8_weight_cache`, off by default): with gradient
+# accumulation the same weights serve every micro-batch of an optimizer step, and quantising a 128-expert table costs more than a
+# GEMM over it (69 GB of traffic for BASELINE config 5's two tables).  Keyed by the tensor's storage and autograd version counter:
+# every in-place update the optimizer (or load_state_dict) makes bumps the version and the next forward quantises again.  Writes
+# through `.data` bypass the counter -- call fp8_weight_cache_clear() after those.  One entry per tensor; the entry of a tensor
+# that is freed goes with its finaliser.
+_FP8_WCACHE = {}
+
+
+def fp8_weight_cache_clear():
+    _FP8_WCACHE.clear()
+
+
+def _quantize_weight_both(t: torch.Tensor, cache: bool):
+    """((q, s) blocks along the last dim, (qt, st) blocks along the second-to-last) of a master weight tensor [.., R, C]."""
+    if not cache:
+        return ops.quantize_mxfp8_both(t)
+    key = (t.data_ptr(), tuple(t.shape), t.dtype)
+    hit = _FP8_WCACHE.get(key)
+    if hit is not None and hit[0] == t._version:
+        return hit[1]
+    out = ops.quantize_mxfp8_both(t)
+    _FP8_WCACHE[key] = (t._version, out)
+    import weakref
+    owner = t._base if t._base is not None else t          # `keys_shared[0]` is a fresh view per call: the parameter owns the entry
+    weakref.finalize(owner, _FP8_WCACHE.pop, key, None)
+    return out
+
+
 class MoEFFNPackedFP8(torch.autograd.Function):
     """MoEFFNPacked with the four row-space expert GEMMs of a step (GEMM 1, GEMM 2, dH, dXs) on the block-scaled fp8 matrix pipe
     (BASELINE config 5; `csmoe_grouped_gemm_mxfp8`): operands quantised to MXFP8 (e4m3 + one e8m0 scale per 32 elements along each
     GEMM's reduction dim), fp32 accumulation, bf16 results.  The weight gradients stay bf16 products of the bf16 activations
     (`csmoe_grouped_wgrad`).  Master weights (fp32 or bf16) are quantised directly, once per use and orientation -- there is no
-    bf16 operand copy.  No counterpart upstream (the reference has no fp8): tolerance is build-defined, tests/test_fp8_gpu.py."""
+    bf16 operand copy -- or, with `cache`, once per parameter version (_quantize_weight_both).  No counterpart upstream (the
+    reference has no fp8): checked against oracle/mxfp8.py, tests/test_fp8_gpu.py."""
 
     @staticmethod
-    def forward(ctx, x2, w, idx, keys, values, bias, act: int, combine_mode: int):
+    def forward(ctx, x2, w, idx, keys, values, bias, act: int, combine_mode: int, cache: bool = False):
         x2 = x2.contiguous()
         if x2.dtype != torch.bfloat16:
             raise ValueError("competesmoe_amd: the fp8 expert path takes bf16 activations (run under bf16 autocast)")
@@ -1022,7 +1052,7 @@ class MoEFFNPackedFP8(torch.autograd.Function):
         bins = ops.bin_tokens(idx, E)
         xs = ops.dispatch_tokens(x2, bins)
         xq, xsc = ops.quantize_mxfp8(xs)
-        (kq_b, ks_b), (kq, ks) = ops.quantize_mxfp8_both(keys)             # backward pair [E, D, F]; forward pair [E, F, D] (reduction over D)
+        (kq_b, ks_b), (kq, ks) = _quantize_weight_both(keys, cache)        # backward pair [E, D, F]; forward pair [E, F, D] (reduction over D)
         b_op = b1 = None
         if bias is not None:
             b_op = bias.to(torch.bfloat16).contiguous()
@@ -1031,7 +1061,7 @@ class MoEFFNPackedFP8(torch.autograd.Function):
                                             want_c2=True, want_c=act != L.ACT_RELU)
         del xq, xsc, kq, ks
         hq, hs = ops.quantize_mxfp8(hact)
-        (vq_b, vs_b), (vq, vs) = ops.quantize_mxfp8_both(values)           # backward pair [E, F, Dout]; forward pair [E, Dout, F]
+        (vq_b, vs_b), (vq, vs) = _quantize_weight_both(values, cache)      # backward pair [E, F, Dout]; forward pair [E, Dout, F]
         y = ops.grouped_gemm_mxfp8(hq, hs, vq, vs, bins.offsets)
         out = ops.combine(y, bins, idx, w, combine_mode, T)
         ctx.saved = (bins, xs, hpre, hact, y, b_op)
@@ -1071,7 +1101,7 @@ class MoEFFNPackedFP8(torch.autograd.Function):
             dhq, dhs = ops.quantize_mxfp8(dh)
             dxs = ops.grouped_gemm_mxfp8(dhq, dhs, kq, ks, bins.offsets)   # keys as stored: dxs = dh @ keys[e]^T
             dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
-        return dx2, dw, None, gk, gv, gb, None, None
+        return dx2, dw, None, gk, gv, gb, None, None, None
 
 
 class DenseFFNFP8(torch.autograd.Function):
@@ -1079,15 +1109,15 @@ class DenseFFNFP8(torch.autograd.Function):
     the pretrain stack's `keys_shared[0]` / `values_shared[0]`, deepseekv2.py:97-105)."""
 
     @staticmethod
-    def forward(ctx, x2, w1, b1, w2, act: int):
+    def forward(ctx, x2, w1, b1, w2, act: int, cache: bool = False):
         x2 = x2.contiguous()
         xq, xsc = ops.quantize_mxfp8(x2)
-        (w1q_b, w1s_b), (w1q, w1s) = ops.quantize_mxfp8_both(w1)           # backward pair [D, Fs]; forward pair [Fs, D]
+        (w1q_b, w1s_b), (w1q, w1s) = _quantize_weight_both(w1, cache)      # backward pair [D, Fs]; forward pair [Fs, D]
         b1o = None if b1 is None else b1.to(torch.bfloat16).contiguous()
         hpre, hact = ops.dense_gemm_mxfp8(xq, xsc, w1q, w1s, bias=b1o, epilogue=L.EPI_BIAS_ACT, act=act, want_c2=True,
                                           want_c=act != L.ACT_RELU)
         hq, hs = ops.quantize_mxfp8(hact)
-        (w2q_b, w2s_b), (w2q, w2s) = ops.quantize_mxfp8_both(w2)           # backward pair [Fs, Dout]; forward pair [Dout, Fs]
+        (w2q_b, w2s_b), (w2q, w2s) = _quantize_weight_both(w2, cache)      # backward pair [Fs, Dout]; forward pair [Dout, Fs]
         y = ops.dense_gemm_mxfp8(hq, hs, w2q, w2s)
         ctx.save_for_backward(x2, hpre, hact, w1, w2, w1q_b, w1s_b, w2q_b, w2s_b)
         ctx.cfg = (act, None if b1 is None else b1.dtype)
@@ -1110,4 +1140,4 @@ class DenseFFNFP8(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dhq, dhs = ops.quantize_mxfp8(dh)
             dx = ops.dense_gemm_mxfp8(dhq, dhs, w1q, w1s)
-        return dx, gw1, gb1, gw2, None
+        return dx, gw1, gb1, gw2, None, None

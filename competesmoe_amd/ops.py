@@ -601,8 +601,9 @@ def dense_wgrad(A: torch.Tensor, B: torch.Tensor, out_dtype=None, force_generic:
     M, Na = A.shape
     Nb = B.shape[1]
     out = torch.empty(Na, Nb, dtype=out_dtype or A.dtype, device=A.device)
-    L.check(lib.csmoe_dense_wgrad(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), M, Na, Nb, out.data_ptr(), Nb, _dt(A),
-                                  _dt(out), 0, int(force_generic), _stream()), "dense_wgrad")
+    with _timed("dense_wgrad_tn", 2.0 * M * Na * Nb):
+        L.check(lib.csmoe_dense_wgrad(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), M, Na, Nb, out.data_ptr(), Nb, _dt(A),
+                                      _dt(out), 0, int(force_generic), _stream()), "dense_wgrad")
     return out
 
 

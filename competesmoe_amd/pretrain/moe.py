@@ -81,6 +81,8 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         self.real_n_experts = 1
         # BASELINE config 5 (no counterpart upstream): the four row-space expert GEMMs of a step on the MXFP8 matrix pipe
         self.fp8_experts = bool(getattr(args, "fp8_experts", False))
+        # keep the quantised weights while the parameters are unchanged (micro-batches of one optimizer step): functional._FP8_WCACHE
+        self.fp8_weight_cache = bool(getattr(args, "fp8_weight_cache", False))
         self.selection_dropout = selection_dropout
         self.expert_dropout = expert_dropout
         self.sel_weight_scale = weight_scale
@@ -182,7 +184,8 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
                 raise ValueError("competesmoe_amd: args.fp8_experts needs bf16 activations (bf16 autocast or a bf16 layer)")
             out = MoEFFNPackedFP8.apply(x2, wk.float().contiguous(), selected_experts.reshape(-1, K).int().contiguous(),
                                         self.keys if keys is None else keys, self.values if values is None else values,
-                                        self.bias if bias is None else bias, self.act_code, L.COMBINE_DOT)
+                                        self.bias if bias is None else bias, self.act_code, L.COMBINE_DOT,
+                                        self.fp8_weight_cache and keys is None and values is None)
             if res is not None:
                 out = res + out.view(res.shape)
             return out.view(*shp[:-1], -1)
@@ -214,7 +217,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         op = op_dtype(x)
         b = None if bias_shared is None else bias_shared[0]
         if self.fp8_experts:
-            y = DenseFFNFP8.apply(x.reshape(-1, shp[-1]).to(op), keys_shared[0], b, values_shared[0], self.act_code)
+            y = DenseFFNFP8.apply(x.reshape(-1, shp[-1]).to(op), keys_shared[0], b, values_shared[0], self.act_code, self.fp8_weight_cache)
             return y.view(*shp[:-1], -1)
         y = DenseFFN.apply(x.reshape(-1, shp[-1]).to(op), keys_shared[0], b, values_shared[0], None, self.act_code, L.B_KN)
         return y.view(*shp[:-1], -1)

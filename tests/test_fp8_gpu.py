@@ -315,3 +315,50 @@ def test_shared_expert_layer_on_the_fp8_pipe_matches_the_oracle_layer(name):
     print(what, {k: f"{v:.2e}" for k, v in errs.items()})
     for k, v in errs.items():
         assert v <= (LOOSE if k.endswith("@near") else MX_OUT if k == "out" else MX_GRAD), (k, errs)
+
+
+def test_quantised_weight_cache_follows_the_parameter_version():
+    """`args.fp8_weight_cache`: the quantised tables are reused while the parameters are unchanged (second micro-batch: no weight
+    quantiser launch, same bits as the uncached layer) and rebuilt after an optimizer step (bits of an uncached layer holding the
+    updated weights)."""
+    import types
+    import torch.nn.functional as F
+    from competesmoe_amd.pretrain import get_moe
+    from competesmoe_amd import functional as Fn
+    D, Fh, E, K, B, N = 256, 384, 8, 2, 2, 160
+    mk = lambda c: types.SimpleNamespace(balance_loss_coef=0.01, fp8_experts=True, fp8_weight_cache=c, n_shared_experts=2, test_only=False)
+    torch.manual_seed(6)
+    plain = get_moe("deepseekv2")(D, E, Fh, n_heads=K, activation=F.relu, log_interval=None, args=mk(False)).to(DEV).train()
+    cached = get_moe("deepseekv2")(D, E, Fh, n_heads=K, activation=F.relu, log_interval=None, args=mk(True)).to(DEV).train()
+    cached.load_state_dict(plain.state_dict())
+    Fn.fp8_weight_cache_clear()
+    x = torch.randn(B, N, D, device=DEV)
+
+    def step(layer):
+        layer.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        ops.profile_start()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = layer(xi)
+        out.float().square().sum().backward()
+        prof = ops.profile_stop()
+        return out.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in layer.parameters() if p.grad is not None], \
+            prof.get("quantize_mxfp8_both", {"calls": 0})["calls"]
+
+    o0, g0, p0, n0 = step(plain)
+    o1, g1, p1, n1 = step(cached)
+    o2, g2, p2, n2 = step(cached)
+    assert n0 == 4 and n1 == 4 and n2 == 0, (n0, n1, n2)
+    for a, b in ((o0, o1), (o0, o2), (g0, g1), (g0, g2)):
+        assert torch.equal(a, b)
+    assert all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(p0, p1, p2))
+    for layer in (plain, cached):                       # one SGD step, in place, as torch.optim does it
+        with torch.no_grad():
+            for p in layer.parameters():
+                if p.grad is not None:
+                    p.add_(p.grad, alpha=-1e-3)
+    o3, g3, p3, n3 = step(plain)
+    o4, g4, p4, n4 = step(cached)
+    assert n4 == 4 and not torch.equal(o3, o0)
+    assert torch.equal(o3, o4) and torch.equal(g3, g4) and all(torch.equal(a, b) for a, b in zip(p3, p4))
+    Fn.fp8_weight_cache_clear()

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--E", type=int, default=64)
     ap.add_argument("--D", type=int, default=4096)
     ap.add_argument("--F", type=int, default=11008)
+    ap.add_argument("--f32-out", action="store_true", help="weight-gradient launches write fp32 (the pretrain stack's master-weight gradients)")
     ap.add_argument("--same-weights", action="store_true", help="every expert points at expert 0's matrices (weight panels stay cache-resident): what the loop does without the weight traffic")
     a = ap.parse_args()
     dev = "cuda"
@@ -51,10 +52,11 @@ def main():
     pb1 = b1.data_ptr() + ar * (F * es)
     if a.same_weights:
         p1, p2 = p1 * 0 + W1.data_ptr(), p2 * 0 + W2.data_ptr()
-    gW1 = torch.empty(E, F, D, device=dev, dtype=bf)
-    gW2 = torch.empty(E, D, F, device=dev, dtype=bf)
-    pg1 = gW1.data_ptr() + ar * (F * D * es)
-    pg2 = gW2.data_ptr() + ar * (D * F * es)
+    gdt = torch.float32 if a.f32_out else bf
+    gW1 = torch.empty(E, F, D, device=dev, dtype=gdt)
+    gW2 = torch.empty(E, D, F, device=dev, dtype=gdt)
+    pg1 = gW1.data_ptr() + ar * (F * D * gW1.element_size())
+    pg2 = gW2.data_ptr() + ar * (D * F * gW2.element_size())
     order = ops.expert_order(off, E) if a.deal else None
     runs = {
         "nt1": (lambda: ops.grouped_gemm(xs, p1, L.B_NK, D, F, off, E, bias_ptrs=pb1, epilogue=L.EPI_BIAS_ACT, act=L.ACT_GELU, want_c2=True), 2.0 * M * D * F),
