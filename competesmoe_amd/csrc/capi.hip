@@ -34,7 +34,11 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
               void* const* c_ptrs, int64_t ldc, int out_dtype, int accumulate, int single_M, void* single_C, hipStream_t st, const int32_t* xcd_order = nullptr);
 int gg8c_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int64_t ldb, void* const* copy_ptrs,
                   const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2, const void* aux,
-                  int64_t ldc, int epilogue, int act, const void* single_B, void* single_copy, const void* single_bias, hipStream_t st);
+                  int64_t ldc, int epilogue, int act, const void* single_B, void* single_copy, const void* single_bias, hipStream_t st,
+                  int row_part);
+int gg8_rowspace_rest(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                      const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                      const void* aux, int64_t ldc, int epilogue, int act, hipStream_t st);
 int k_quantize_mxfp8(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, int transpose,
                      void* q, void* s, hipStream_t st);
 int k_quantize_mxfp8_both(const void* const* x_ptrs, const void* x_single, int E, int64_t ldx, int R, int C, int in_dtype, void* q,
@@ -640,6 +644,17 @@ int csmoe_grouped_gemm_f32w(const void* A, int64_t lda, const void* const* b_ptr
                     "(N=%d Kd=%d); cast the weights and use csmoe_grouped_gemm", N, Kd);
     return CSMOE_ERR_UNSUPPORTED;
   }
+  // With a bf16 copy requested: the launch over every expert's FIRST row tile converts the fp32 masters in its tile fill and writes
+  // the copy; the other row tiles run the LDS-DMA kernel over that copy (same stream: the copy is complete when they start).
+  // CSMOE_F32W_SPLIT=0 (A/B): every row tile converts, as in round 2.
+  static const bool split = [] { const char* e = getenv("CSMOE_F32W_SPLIT"); return !e || atoi(e) != 0; }();
+  if (b_copy_ptrs && split && (int64_t)Kd * N * 2 < 0x80000000ll) {
+    if (int rc = gg8c_rowspace(A, lda, b_ptrs, ldb, b_copy_ptrs, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act, nullptr,
+                               nullptr, nullptr, (hipStream_t)stream, 1))
+      return rc;
+    return gg8_rowspace_rest(A, lda, (const void* const*)b_copy_ptrs, CSMOE_B_KN, N, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc,
+                             epilogue, act, (hipStream_t)stream);
+  }
   return gg8c_rowspace(A, lda, b_ptrs, ldb, b_copy_ptrs, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act, nullptr,
-                       nullptr, nullptr, (hipStream_t)stream);
+                       nullptr, nullptr, (hipStream_t)stream, 0);
 }

@@ -154,26 +154,29 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   }
   return v;
 }
-__device__ __forceinline__ int grouped_total_tiles(const int32_t* offsets, int E, int single_M, int BMt, int nct, int lane) {
+// `part` selects which row tiles of every expert a launch covers: 0 all, 1 the first only, 2 all but the first (the fp32-master GEMM
+// converts the weights in the launch over the first row tiles and runs the others from the bf16 copy that launch wrote)
+__device__ __forceinline__ int part_tiles(int mt_e, int part) { return part == 1 ? min(mt_e, 1) : part == 2 ? max(mt_e - 1, 0) : mt_e; }
+__device__ __forceinline__ int grouped_total_tiles(const int32_t* offsets, int E, int single_M, int BMt, int nct, int lane, int part = 0) {
   int total = 0;
   for (int base = 0; base < E; base += 64) {
     int e = base + lane;
     int cnt = 0;
     if (e < E) cnt = offsets ? (offsets[e + 1] - offsets[e]) : single_M;
-    int tiles = ((cnt + BMt - 1) / BMt) * nct;
+    int tiles = part_tiles((cnt + BMt - 1) / BMt, part) * nct;
     tiles = wave_incl_scan(tiles, lane);
     total += __shfl(tiles, 63, 64);
   }
   return total;
 }
 __device__ __forceinline__ bool grouped_find_tile(const int32_t* offsets, int E, int single_M, int BMt, int nct, int v, int lane,
-                                                  TilePos& out) {
+                                                  TilePos& out, int part = 0) {
   int acc = 0;
   for (int base = 0; base < E; base += 64) {
     int e = base + lane;
     int o0 = 0, o1 = 0;
     if (e < E) { o0 = offsets ? offsets[e] : 0; o1 = offsets ? offsets[e + 1] : single_M; }
-    int mt_e = (o1 - o0 + BMt - 1) / BMt;
+    int mt_e = part_tiles((o1 - o0 + BMt - 1) / BMt, part);
     int incl = wave_incl_scan(mt_e * nct, lane) + acc;
     unsigned long long hit = __ballot(incl > v);
     if (hit) {
@@ -184,7 +187,7 @@ __device__ __forceinline__ bool grouped_find_tile(const int32_t* offsets, int E,
       out.e = base + src;
       out.o0 = __shfl(o0, src, 64);
       out.o1 = __shfl(o1, src, 64);
-      out.mt = local % mte;
+      out.mt = local % mte + (part == 2 ? 1 : 0);
       out.nt = local / mte;
       return true;
     }

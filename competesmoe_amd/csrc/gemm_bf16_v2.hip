@@ -73,10 +73,10 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
   const int nct = (p.NC + BN2 - 1) / BN2;
   if (MODE == 0) {
     TilePos tp;
-    const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BM2, nct, lane);
+    const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BM2, nct, lane, p.row_part);
     if ((int)blockIdx.x >= total) return;
     const int v = xcd_remap(blockIdx.x, total);
-    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM2, nct, v, lane, tp)) return;
+    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM2, nct, v, lane, tp, p.row_part)) return;
     e = tp.e;
     row0 = tp.o0 + tp.mt * BM2; rows = min(BM2, tp.o1 - row0);
     tc0 = tp.nt * BN2;
@@ -528,11 +528,12 @@ int set_lds2(K kern) {
 
 }  // namespace
 
-int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
-                 const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
-                 const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
-                 hipStream_t st) {
+static int rowspace_launch(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                           const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                           const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
+                           hipStream_t st, int row_part) {
   FastArgs p{};
+  p.row_part = row_part;
   p.single_M = M; p.single_B = single_B; p.single_bias = single_bias;
   p.R = A; p.ld_r = lda; p.c_ptrs_in = b_ptrs; p.ld_c = ldb; p.bias_ptrs = bias_ptrs; p.offsets = offsets; p.E = E;
   p.NC = N; p.Kd = Kd; p.C = C; p.C2 = C2; p.aux = aux; p.ldc = ldc; p.epilogue = epilogue; p.act = act;
@@ -578,4 +579,20 @@ int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_la
   if (sp == BAL) LAUNCH_SCHED(BAL); else LAUNCH_SCHED(WIDE);
   CSMOE_CHECK_LAUNCH("grouped_gemm(bf16 v2)");
   return CSMOE_OK;
+}
+
+int gg8_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                 const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                 const void* aux, int64_t ldc, int epilogue, int act, const void* single_B, const void* single_bias,
+                 hipStream_t st) {
+  return rowspace_launch(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act, single_B,
+                         single_bias, st, 0);
+}
+
+// every row tile of every expert EXCEPT its first (the fp32-master GEMM's second launch, gemm_bf16_v2c.hip)
+int gg8_rowspace_rest(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,
+                      const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2,
+                      const void* aux, int64_t ldc, int epilogue, int act, hipStream_t st) {
+  return rowspace_launch(A, lda, b_ptrs, b_layout, ldb, bias_ptrs, offsets, E, M, N, Kd, C, C2, aux, ldc, epilogue, act, nullptr,
+                         nullptr, st, 2);
 }

@@ -21,7 +21,11 @@
 //     instructions and 96 KiB per CU where the bf16 kernel has 8 and 64 KiB, and the bf16 loop is already paced by that stream
 //     (DESIGN.md section 3, round-2 stamps: the DMA stream alone takes 1.21 us of a 1.7 us K-tile);
 //   * the tiles of an expert's FIRST row tile also store the converted pieces to a bf16 copy of the weights (`b_copy`), which the two
-//     backward GEMMs of the step read through the plain LDS-DMA kernels -- experts without rows write nothing and are read by nobody.
+//     backward GEMMs of the step read through the plain LDS-DMA kernels -- experts without rows write nothing and are read by nobody;
+//   * round 3: with a copy requested, ONLY the first row tiles run this kernel (`row_part` = 1); the expert's other row tiles follow
+//     in a second launch of the LDS-DMA kernel over the copy (gg8_rowspace_rest, stream order makes the copy visible).  At the
+//     headline shape an expert has ~4 row tiles, so 3/4 of the work runs at the bf16 kernel's rate and the fp32 panel of an
+//     (expert, column tile) is fetched once instead of by four workgroups.
 #include "gemm_epilogue.h"
 #include <algorithm>
 
@@ -41,6 +45,7 @@ struct CvtArgs {
   int NC, Kd;
   void* C; void* C2; const void* aux; int64_t ldc;
   int epilogue, act;
+  int row_part;                                                           // 0 every row tile, 1 every expert's first only (common.h)
 };
 
 __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
@@ -58,11 +63,11 @@ __global__ void __launch_bounds__(512, 2) gg8c_kernel(CvtArgs p) {
   int e, row0, rows, tc0, mt;
   const int nct = (p.NC + BNc - 1) / BNc;
   {
-    const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BMc, nct, lane);
+    const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BMc, nct, lane, p.row_part);
     if ((int)blockIdx.x >= total) return;
     const int v = xcd_remap(blockIdx.x, total);
     TilePos tp;
-    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BMc, nct, v, lane, tp)) return;
+    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BMc, nct, v, lane, tp, p.row_part)) return;
     e = tp.e; mt = tp.mt;
     row0 = tp.o0 + tp.mt * BMc; rows = min(BMc, tp.o1 - row0);
     tc0 = tp.nt * BNc;
@@ -276,13 +281,15 @@ __global__ void __launch_bounds__(512, 2) gg8c_kernel(CvtArgs p) {
 
 int gg8c_rowspace(const void* A, int64_t lda, const void* const* b_ptrs, int64_t ldb, void* const* copy_ptrs,
                   const void* const* bias_ptrs, const int32_t* offsets, int E, int M, int N, int Kd, void* C, void* C2, const void* aux,
-                  int64_t ldc, int epilogue, int act, const void* single_B, void* single_copy, const void* single_bias, hipStream_t st) {
+                  int64_t ldc, int epilogue, int act, const void* single_B, void* single_copy, const void* single_bias, hipStream_t st,
+                  int row_part) {
   CvtArgs p{};
+  p.row_part = row_part;
   p.R = A; p.ld_r = lda; p.b_ptrs = b_ptrs; p.single_B = single_B; p.ld_c = ldb; p.copy_ptrs = copy_ptrs; p.single_copy = single_copy;
   p.bias_ptrs = bias_ptrs; p.single_bias = single_bias; p.offsets = offsets; p.E = E; p.single_M = M;
   p.NC = N; p.Kd = Kd; p.C = C; p.C2 = C2; p.aux = aux; p.ldc = ldc; p.epilogue = epilogue; p.act = act;
   const int nct = (N + BNc - 1) / BNc;
-  const int64_t grid = (int64_t)nct * ((M + BMc - 1) / BMc + E);
+  const int64_t grid = row_part == 1 ? (int64_t)nct * E : (int64_t)nct * ((M + BMc - 1) / BMc + E);
   if (grid <= 0) return CSMOE_OK;
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_gemm_f32w: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   static bool done = false;
