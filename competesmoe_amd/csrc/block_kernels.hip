@@ -71,32 +71,51 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      float s = 0.f;
+      // Row statistics as a cascade: every 16-byte chunk is summed as an fp32 tree, the chunk sums are accumulated and reduced across
+      // the wave in fp64 (one convert + one fp64 add per chunk: per-element fp64 cost 0.07 ms at the headline shape, this form none).
+      // The reference's CPU LayerNorm keeps its moments to better than one fp32 ulp (cascade sums too), and plain fp32 accumulation
+      // here put 1 of 6144 bf16 outputs of the block fixtures on the other side of a rounding boundary -- enough, in a 96-token
+      // fixture, for 1e-3 in the gradients of the expert that token is routed to (tools/block_grad_probe.py).  With these moments the
+      // fixture's xn is reproduced bit for bit.
+      double s = 0.0;
       if (live[h]) {
 #pragma unroll
         for (int c = 0; c < CPL_MAX; ++c) {
           if (c * 64 + lane < nch) {
             float f[N];
             Chunk<T>::unpack(v[h][c], f);
+            float t[N];
 #pragma unroll
-            for (int e = 0; e < N; ++e) s += f[e];
+            for (int e = 0; e < N; ++e) t[e] = f[e];
+#pragma unroll
+            for (int w = N / 2; w > 0; w >>= 1)
+#pragma unroll
+              for (int e = 0; e < w; ++e) t[e] += t[e + w];
+            s += (double)t[0];
           }
         }
       }
-      mean[h] = wave_sum(s) / (float)D;
-      float q = 0.f;
+      const double mean_d = wave_sum(s) / (double)D;
+      mean[h] = (float)mean_d;
+      double q = 0.0;
       if (live[h]) {
 #pragma unroll
         for (int c = 0; c < CPL_MAX; ++c) {
           if (c * 64 + lane < nch) {
             float f[N];
             Chunk<T>::unpack(v[h][c], f);
+            float t[N];
 #pragma unroll
-            for (int e = 0; e < N; ++e) { const float d = f[e] - mean[h]; q += d * d; }
+            for (int e = 0; e < N; ++e) { const float d = f[e] - mean[h]; t[e] = d * d; }
+#pragma unroll
+            for (int w = N / 2; w > 0; w >>= 1)
+#pragma unroll
+              for (int e = 0; e < w; ++e) t[e] += t[e + w];
+            q += (double)t[0];
           }
         }
       }
-      rstd[h] = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+      rstd[h] = (float)(1.0 / sqrt(wave_sum(q) / (double)D + (double)eps));
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {

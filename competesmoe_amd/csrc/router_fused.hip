@@ -18,12 +18,16 @@
 
 namespace {
 
-constexpr int RF_ROWS = 64;           // token rows per workgroup
+#ifndef CSMOE_RF_WAVES
+#define CSMOE_RF_WAVES 4
+#endif
+constexpr int RF_WAVES = CSMOE_RF_WAVES;   // waves per workgroup, 16 token rows each
+constexpr int RF_ROWS = 16 * RF_WAVES;     // token rows per workgroup
 constexpr int RF_KCH = 256;           // K-chunk staged in LDS
 constexpr int RF_LD = RF_KCH + 8;     // bf16 elements per staged gate row (528 B)
 
 template <int NE>                     // NE = ceil(E / 16) column blocks
-__global__ void __launch_bounds__(256) gate_select_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wg, int T, int D, int E,
+__global__ void __launch_bounds__(64 * RF_WAVES) gate_select_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wg, int T, int D, int E,
                                                           int K, int mode, int round_sum_bf16, float sel_param,
                                                           bf16* __restrict__ logits, float* __restrict__ softmax,
                                                           int32_t* __restrict__ idx, float* __restrict__ w,
@@ -37,9 +41,10 @@ __global__ void __launch_bounds__(256) gate_select_kernel(const bf16* __restrict
   const int my_row = min(row0 + i16, T - 1);                  // rows past the end re-read the last row; their results are dropped
   const bf16* xrow = x + (int64_t)my_row * D + 8 * g;
 
-  // staging map: thread -> (gate row, 16-byte segment) of a chunk: 32 threads per row, 8 rows per pass
+  // staging map: thread -> (gate row, 16-byte segment) of a chunk: 32 threads per row, 2 rows per wave and pass
   const int s_seg = tid & 31, s_row = tid >> 5;
-  constexpr int NPASS = NE * 2;                               // NE*16 rows / 8
+  constexpr int RPP = 2 * RF_WAVES;                           // gate rows per pass
+  constexpr int NPASS = NE * 16 / RPP;
   bf16x8 wreg[NPASS];
   bf16x8 a[3][8];                                             // ring: chunk ch in a[ch % 3], chunks ch+1 and ch+2 in flight
   f32x4 acc[NE];
@@ -50,13 +55,13 @@ __global__ void __launch_bounds__(256) gate_select_kernel(const bf16* __restrict
   auto load_w = [&](int ch) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const int e = p * 8 + s_row, k = ch * RF_KCH + s_seg * 8;
+      const int e = p * RPP + s_row, k = ch * RF_KCH + s_seg * 8;
       wreg[p] = (e < E && k < D) ? *(const bf16x8*)(wg + (int64_t)e * D + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) *(bf16x8*)(wbuf + buf * WB + (p * 8 + s_row) * RF_LD + s_seg * 8) = wreg[p];
+    for (int p = 0; p < NPASS; ++p) *(bf16x8*)(wbuf + buf * WB + (p * RPP + s_row) * RF_LD + s_seg * 8) = wreg[p];
   };
   auto load_a = [&](bf16x8 (&av)[8], int ch) {
 #pragma unroll
@@ -80,7 +85,11 @@ __global__ void __launch_bounds__(256) gate_select_kernel(const bf16* __restrict
       }
     }
     if (more) store_w((ch + 1) & 1);                           // the other buffer: last read in iteration ch - 1, behind a barrier
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() also waits vmcnt(0), i.e. for the x chunk fetched two steps ahead -- it left ONE chunk in
+    // flight per wave across every step boundary instead of two
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
   load_w(0);
@@ -102,7 +111,7 @@ __global__ void __launch_bounds__(256) gate_select_kernel(const bf16* __restrict
     for (int j = 0; j < 4; ++j) lrow[(4 * g + j) * 65 + c * 16 + i16] = (float)(bf16)acc[c][j];
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  int32_t* hist = (int32_t*)((float*)smem + 4 * 16 * 65);      // [64] behind the four logit tiles
+  int32_t* hist = (int32_t*)((float*)smem + RF_WAVES * 16 * 65);      // [64] behind the logit tiles
   if (block_hist) {
     if (tid < 64) hist[tid] = 0;
     __syncthreads();
@@ -147,8 +156,8 @@ int k_gate_select(const void* x, const void* wg, int T, int D, int E, int K, int
                   void* logits, float* softmax, int32_t* idx, float* w, int32_t* block_hist, hipStream_t st) {
   if (T == 0) return CSMOE_OK;
   const int ne = (E + 15) / 16;
-  const dim3 grid(k_gate_select_blocks(T)), block(256);
-  const size_t lds = std::max<size_t>((size_t)2 * ne * 16 * RF_LD * 2, (size_t)4 * 16 * 65 * 4 + 256);
+  const dim3 grid(k_gate_select_blocks(T)), block(64 * RF_WAVES);
+  const size_t lds = std::max<size_t>((size_t)2 * ne * 16 * RF_LD * 2, (size_t)RF_WAVES * 16 * 65 * 4 + 256);
 #define GS_LAUNCH(NE)                                                                                                    \
   hipLaunchKernelGGL((gate_select_kernel<NE>), grid, block, lds, st, (const bf16*)x, (const bf16*)wg, T, D, E, K, mode,  \
                      round_sum_bf16, sel_param, (bf16*)logits, softmax, idx, w, block_hist)

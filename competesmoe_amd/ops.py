@@ -342,7 +342,7 @@ def dispatch_tokens(x2: torch.Tensor, bins: Bins) -> torch.Tensor:
 def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
     D = dxs.shape[1]
     dx = torch.empty(T, D, dtype=dxs.dtype, device=dxs.device)
-    with _timed("dispatch_rows_bwd", (T + bins.n) * D * dxs.element_size()):
+    with _timed("dispatch_rows_bwd", (T * (2 if add is not None else 1) + bins.n) * D * dxs.element_size()):     # `add` is one more [T, D] read
         L.check(lib.csmoe_dispatch_rows_bwd(dxs.data_ptr(), bins.slot_of.data_ptr(), bins.K, _ptr(add), dx.data_ptr(), T, D,
                                             _dt(dxs), _stream()), "dispatch_rows_bwd")
     return dx

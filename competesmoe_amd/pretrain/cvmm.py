@@ -65,7 +65,7 @@ class _CVMM(torch.autograd.Function):
             out = ops.combine(ys, rbins, None, weight.reshape(-1, Kr).to(op).float().contiguous(), L.COMBINE_DOT, bins.n // Kr)
         else:                   # back to the flat (t*K+k) order
             out = ops.dispatch_rows(ys, ops.Bins(None, None, bins.slot_of, None, bins.n, bins.E, 1))
-        ctx.save_for_backward(xs, k_op, ys if weight is not None else None, weight)
+        ctx.save_for_backward(xs, k_op, None, weight)
         ctx.meta = (bins, rows_are_slots, ptrs, keys.dtype, x.shape, x.dtype, T, rbins)
         return out
 
@@ -76,15 +76,32 @@ class _CVMM(torch.autograd.Function):
         E, Din, Dout = k_op.shape
         g = g.reshape(-1, Dout).to(k_op.dtype).contiguous()
         dw = None
+        ar = ops.cached_arange(E, g.device)
         if weight is not None:
-            gs, dwf = ops.combine_bwd(g, ys, rbins, weight.reshape(-1, rbins.K).to(k_op.dtype).float().contiguous())
-            dw = dwf.view_as(weight).to(weight.dtype)
+            # CVMM.backward of the weighted call (cvmm.py:497-547), rounding points included: the weight gradient multiplies the rows
+            # of x with round(w * g); the input gradient sends the UNSCALED upstream rows through the product, rounds, multiplies by
+            # the op-dtype weight and rounds again; d w = <unscaled rounded product, x row>, returned unrounded.
+            Kr = rbins.K
+            wq = weight.reshape(-1, Kr).to(k_op.dtype).float().contiguous()
+            gs, _ = ops.combine_bwd(g, None, rbins, wq, want_dw=False)
+            gu = ops.dispatch_tokens(g, rbins)
+            w_rows = wq.reshape(-1)[rbins.perm.long()].contiguous()
+            dot_cols = ops.rowdot_cols(bins.n, Din, Dout, Dout, Dout, Din, k_op.dtype)
+            if dot_cols:
+                dot = torch.empty(bins.n, dot_cols, dtype=torch.float32, device=g.device)
+                dxs = ops.grouped_gemm(gu, ptrs, L.B_NK, Dout, Din, bins.offsets, E, epilogue=L.EPI_ACTGRAD_ROWSCALE, act=L.ACT_NONE,
+                                       aux=xs, row_scale=w_rows, row_dot=dot)
+                dwr = ops.finish_row_dot(dot)
+            else:               # fp32 / unaligned shapes (generic kernel: no dot table): the same arithmetic in three steps
+                prod = ops.grouped_gemm(gu, ptrs, L.B_NK, Dout, Din, bins.offsets, E)
+                dwr = (prod.float() * xs.float()).sum(-1)
+                dxs = (prod.float() * w_rows.unsqueeze(-1)).to(prod.dtype)
+            dw = dwr[rbins.slot_of.long()].view_as(weight).to(weight.dtype)
         else:
             gs = ops.dispatch_rows(g, ops.Bins(None, None, bins.perm, None, bins.n, bins.E, 1))
+            dxs = ops.grouped_gemm(gs, ptrs, L.B_NK, Dout, Din, bins.offsets, E)
         gk = torch.empty(E, Din, Dout, dtype=kd, device=g.device)
-        ar = ops.cached_arange(E, g.device)
         ops.grouped_wgrad(xs, gs, bins.offsets, E, gk, gk.data_ptr() + ar * (Din * Dout * gk.element_size()))
-        dxs = ops.grouped_gemm(gs, ptrs, L.B_NK, Dout, Din, bins.offsets, E)
         if rows_are_slots:
             dx = ops.dispatch_rows(dxs, ops.Bins(None, None, bins.slot_of, None, bins.n, bins.E, 1))
         else:

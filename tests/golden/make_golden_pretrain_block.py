@@ -100,9 +100,25 @@ def run_case(name, moe_name, bf16, competition=False, B=2, N=48, D=64, E=8, F_=3
         dy = torch.randn(B, N, D, generator=g)
         xg = x.clone().requires_grad_(True)
         layer.pkm.regularization_present = True
-        with G.amp(bf16, upcasts):
-            out = layer(xg, None, **kw)
-            reg = layer.pkm.get_reg_loss()
+        # the reference's own top-k index results (gate first, affinity second on a competition step): torch.topk's choice among exactly
+        # tied bf16 scores is unspecified, so the fixture records it (as tests/golden/make_golden_pretrain.py does)
+        topk_idx = []
+        orig_topk = torch.topk
+
+        def spy_topk(*a_, **k_):
+            r = orig_topk(*a_, **k_)
+            topk_idx.append(r[1].detach().clone())
+            return r
+        torch.topk = spy_topk
+        try:
+            with G.amp(bf16, upcasts):
+                out = layer(xg, None, **kw)
+                reg = layer.pkm.get_reg_loss()
+        finally:
+            torch.topk = orig_topk
+        fx["selected_experts"] = topk_idx[0]
+        if competition and len(topk_idx) > 1:
+            fx["aff_selected"] = topk_idx[-1]
         fx["meta"]["autocast_fp32_upcasts"] = dict(upcasts)
         h.remove()
         loss = (out.float() * dy).sum() + sum(v.float() for v in reg.values())

@@ -131,21 +131,62 @@ def test_block_matches_reference_golden(case, tag):
     same = (sel.sort(-1).values == gold.sort(-1).values).all(-1).reshape(-1)
     # bf16 competition: the affinities are bf16 means of softplus (~3 significant digits) -> near-ties between experts are
     # common and resolve with the accumulation order; the same slack as tests/test_llava_modules_gpu.py
-    need = 0.99 if tag == "fp32" else (0.85 if m["competition"] else 0.93)
+    need = 0.99 if tag == "fp32" else (0.90 if m["competition"] else 0.99)     # observed: 88 of 96 rows / all rows
     assert same.float().mean() >= need
     o, go = out.detach().cpu().reshape(-1, m["D"]), fx["output"].reshape(-1, m["D"])
     assert rel_l2(o[same], go[same]) <= r
-    if bool(same.all()):
-        assert abs(float(aux.detach()) - float(fx["aux_loss"])) <= 4 * r * max(1.0, abs(float(fx["aux_loss"])))
-        assert rel_l2(x.grad.cpu(), fx["x_mid_grad"]) <= 4 * r
-        assert rel_l2(blk.layer_norm2.weight.grad.cpu(), fx["ln_grads"]["weight"]) <= 8 * r
-        assert rel_l2(blk.layer_norm2.bias.grad.cpu(), fx["ln_grads"]["bias"]) <= 8 * r
-        assert rel_l2(blk.moelayer.gate.weight.grad.cpu(), fx["moe_grads"]["gate.weight"]) <= 8 * r + 1e-4
-        for k, gref in fx["moe_grads"].items():
-            if gref is None or not k.startswith("experts."):
-                continue
-            p = dict(blk.moelayer.named_parameters())[k]
-            assert rel_l2(p.grad.cpu(), gref) <= 8 * r, k
+    # bf16 gradients against the fixture, observed: dx 1.9e-3, LayerNorm weight / bias 6.5e-3 / 4.8e-3 (the reference's CPU LayerNorm
+    # backward, see below), gate the reference's bits, experts 1.8e-4 (1.9e-3 on the competition step)
+    gdx, gln, ggate, gexp = (4 * r, 8 * r, 8 * r + 1e-4, 8 * r) if tag == "fp32" else (4e-3, 1e-2, 1e-3, 4e-3)
+    ref_aux, ref_dx, ref_ln, ref_moe = fx["aux_loss"], fx["x_mid_grad"], fx["ln_grads"], fx["moe_grads"]
+    if not bool(same.all()):
+        # rows routed unlike the reference's run (exact ties of its bf16 affinities): gradients against the oracle, pinned by
+        # tests/test_block_oracle_golden.py, evaluated with the KERNEL's indices -- no fixture's backward goes unchecked
+        assert m["competition"] and tag == "bf16", "tie rows are expected on the bf16 competition step only"
+        from tests.test_block_oracle_golden import oracle_block, experts_of
+        xo = fx["x_mid"].clone().requires_grad_(True)
+        lnw, lnb = (fx["ln_state"][k].clone().requires_grad_(True) for k in ("weight", "bias"))
+        wgo = fx["moe_state"]["gate.weight"].clone().requires_grad_(True)
+        ex = experts_of(fx)
+        o_out, o_aux, _, _, _ = oracle_block(fx, xo, lnw, lnb, wgo, ex, aff_idx=sel.view(m["B"], m["N"], -1))
+        ((o_out.float() * fx["dy"].float()).sum() + o_aux.float()).backward()
+        assert rel_l2(o, o_out.detach().reshape(-1, m["D"])) <= r
+        ref_aux, ref_dx, ref_ln = o_aux.detach(), xo.grad, {"weight": lnw.grad, "bias": lnb.grad}
+        ref_moe = {"gate.weight": wgo.grad}
+        for i, ts in enumerate(ex):
+            for t, k in zip(ts, ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")):
+                ref_moe[f"experts.{i}.{k}"] = t.grad
+    if tag == "bf16":
+        # What the loose LayerNorm / dx bounds above are made of: the reference's CPU bf16 LayerNorm BACKWARD is itself inexact -- from
+        # the reference's own dxn (the pinned oracle's, bit-equal to the fixture everywhere else), LayerNorm backward with fp32
+        # accumulation (what the CUDA kernel does, and this one) differs from the fixture by exactly the numbers observed here (dx
+        # 1.85e-3, d gamma 6.5e-3, d beta 4.7e-3: 41 of its 64 d beta elements are not the correctly rounded column sums).  So the
+        # sharp check is against THAT: the oracle's dxn through an fp32 LayerNorm backward, rounded once.
+        from tests.test_block_oracle_golden import oracle_block, experts_of
+        xo = fx["x_mid"].clone().requires_grad_(True)
+        lnw, lnb = (fx["ln_state"][k].clone().requires_grad_(True) for k in ("weight", "bias"))
+        o_out, o_aux, _, _, o_xn = oracle_block(fx, xo, lnw, lnb, fx["moe_state"]["gate.weight"].clone().requires_grad_(True), experts_of(fx),
+                                               aff_idx=None if bool(same.all()) else sel.view(m["B"], m["N"], -1))
+        o_xn.retain_grad()
+        ((o_out.float() * fx["dy"].float()).sum() + o_aux.float()).backward()
+        xf = fx["x_mid"].float().requires_grad_(True)
+        gf, bf_ = (fx["ln_state"][k].float().requires_grad_(True) for k in ("weight", "bias"))
+        F.layer_norm(xf, (m["D"],), gf, bf_, m["eps"]).backward(o_xn.grad.float())
+        dx_exact = (xf.grad.bfloat16().float() + fx["dy"].float()).bfloat16()
+        sharp = {"dx": rel_l2(x.grad.cpu(), dx_exact), "ln.weight": rel_l2(blk.layer_norm2.weight.grad.cpu(), gf.grad.bfloat16()),
+                 "ln.bias": rel_l2(blk.layer_norm2.bias.grad.cpu(), bf_.grad.bfloat16())}
+        print("block", case, tag, "against fp32-accumulated LayerNorm backward of the oracle's dxn:", {k: f"{v:.2e}" for k, v in sharp.items()})
+        # observed: smoe / router step 0 (the bits of exact arithmetic on the reference's dxn); competition step 8e-4 / 1.9e-3 / 1.2e-3
+        # (its dxn carries the E dense streams discussed in tests/test_llava_modules_gpu.py)
+        assert all(v <= (3e-3 if m["competition"] else 1e-6) for v in sharp.values()), sharp
+    assert abs(float(aux.detach()) - float(ref_aux)) <= 4 * r * max(1.0, abs(float(ref_aux)))
+    errs = {"dx": rel_l2(x.grad.cpu(), ref_dx), "ln.weight": rel_l2(blk.layer_norm2.weight.grad.cpu(), ref_ln["weight"]),
+            "ln.bias": rel_l2(blk.layer_norm2.bias.grad.cpu(), ref_ln["bias"]),
+            "gate": rel_l2(blk.moelayer.gate.weight.grad.cpu(), ref_moe["gate.weight"])}
+    params = dict(blk.moelayer.named_parameters())
+    errs["experts"] = max(rel_l2(params[k].grad.cpu(), g) for k, g in ref_moe.items() if g is not None and k.startswith("experts."))
+    print("block", case, tag, "rows routed alike", float(same.float().mean()), {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["dx"] <= gdx and errs["ln.weight"] <= gln and errs["ln.bias"] <= gln and errs["gate"] <= ggate and errs["experts"] <= gexp, errs
     # residual must have been taken by the combine epilogue, not by a separate add
     assert blk.moelayer._residual is None and blk.moelayer._pre_logits is None
 

@@ -53,6 +53,10 @@ def test_pretrain_block_matches_reference(case, tag):
     x = fx["mid"].to(DEV).requires_grad_(True)
     dy = fx["dy"].to(DEV)
     assert blk._fusable(x) or bf16 is None
+    spy = {}
+    if hasattr(layer, "ffn"):        # the indices the kernel routed with (for the tie rows of deepseekv3, below)
+        ffn0 = layer.ffn
+        layer.ffn = lambda xx, sel, ww, *a, **k: (spy.setdefault("idx", sel.detach().cpu().long()), ffn0(xx, sel, ww, *a, **k))[1]
     if bf16:
         with torch.autocast("cuda", dtype=torch.bfloat16):
             assert blk._fusable(x)
@@ -91,7 +95,20 @@ def test_pretrain_block_matches_reference(case, tag):
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
                 continue
             assert rel_l2(p.grad, g.to(DEV)) <= 4e-5, (name, rel_l2(p.grad, g.to(DEV)))
-    elif routed_same:
+    elif not routed_same:
+        # a row routed unlike the reference's run (an exact tie of its bf16 scores): gradients against the oracle pinned by
+        # tests/test_block_oracle_golden.py under the KERNEL's indices -- no fixture's backward goes unchecked
+        assert case == "deepseekv3", "tie rows are expected for the sigmoid scores of deepseekv3 only"
+        from tests.test_block_oracle_golden import oracle_pretrain_block_deepseek
+        o_out, _, o_xg, o_g = oracle_pretrain_block_deepseek(fx, spy["idx"])
+        assert rel_l2(out.detach().cpu(), o_out) <= 2e-4, rel_l2(out.detach().cpu(), o_out)
+        errs = {"dx": rel_l2(x.grad.cpu(), o_xg), "norm2.weight": rel_l2(blk.norm2.weight.grad.cpu(), o_g["norm2.weight"]),
+                "norm2.bias": rel_l2(blk.norm2.bias.grad.cpu(), o_g["norm2.bias"])}
+        for name in ("keys", "values", "keys_shared", "values_shared", "w_gate"):
+            errs[name] = rel_l2(getattr(layer, name).grad.cpu(), o_g[name])
+        print("pretrain block", case, tag, "against the oracle under the kernel's indices:", {k: f"{v:.2e}" for k, v in errs.items()})
+        assert all(v <= 2.5e-3 for v in errs.values()), errs
+    else:
         assert x.grad.dtype == torch.float32
         gx, gln, gw = (1e-4, 1e-4, 1e-4) if not comp else (2e-3, 6e-3, 3e-4)
         assert rel_l2(x.grad, fx["mid_grad"].to(DEV)) <= gx

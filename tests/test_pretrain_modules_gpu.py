@@ -194,17 +194,20 @@ def test_moe_attention_projection_matches_golden(tag):
         out = layer.compute_moe(x, sel)
     assert out.shape == fx["output"].shape and out.dtype == fx["output"].dtype
     same = (sel.raw_sel_index.cpu().long().sort(-1).values == fx["sel_index"].sort(-1).values).all(-1)      # [B, N, heads]
-    assert float((~same).float().mean()) <= (0.0 if not bf16 else 0.04)
+    assert bool(same.all()), "the fixture has no tied scores: every row must route as the reference's"
     assert rel_l2(sel.raw_sel.float().cpu(), fx["gate_logits"].float()) <= (1e-5 if not bf16 else 4e-3)
     ok = same.to(DEV)
     o, g = out.detach()[ok].double(), fx["output"].to(DEV)[ok].double()
     assert rel_l2(o, g) <= (1e-5 if not bf16 else 2e-3), rel_l2(o, g)
     (out.float() * fx["dy"].to(DEV)).sum().backward()
-    if bool(same.all()):
-        gt = 4e-5 if not bf16 else 8e-3
-        assert rel_l2(x.grad, fx["x_grad"].to(DEV)) <= gt
-        for name in ("experts", "expert_sel", "expert_embeddings"):
-            assert rel_l2(getattr(layer, name).grad, fx["grads"][name].to(DEV)) <= gt, name
+    # bf16, observed: dx 2.7e-3, experts 5.3e-4, expert_sel 3.9e-3, expert_embeddings 4.5e-3.  The products (cvmm forward and backward)
+    # reproduce the reference's bits since round 3 (test_cvmm_api_matches_the_reference_kernels); the rest enters through the cosine
+    # gate -- torch ops in both runs (normalize, two matmuls, softmax in bf16), on the CPU for the reference and on the GPU here: the
+    # gate's own parameters carry the largest error, the expert weights the smallest
+    gt = 4e-5 if not bf16 else 6e-3
+    assert rel_l2(x.grad, fx["x_grad"].to(DEV)) <= gt
+    for name in ("experts", "expert_sel", "expert_embeddings"):
+        assert rel_l2(getattr(layer, name).grad, fx["grads"][name].to(DEV)) <= gt, name
     assert layer.w_gate.grad is None            # the linear gate is allocated but unused by this layer, as upstream
 
 
@@ -257,7 +260,9 @@ def test_cvmm_api_matches_the_reference_kernels(tag):
     assert rel_l2(scores, fx["scores"].to(DEV)) <= tol, rel_l2(scores, fx["scores"].to(DEV))
     assert rel_l2(out, fx["output"].to(DEV)) <= tol, rel_l2(out, fx["output"].to(DEV))
     (out.float() * fx["dy"].to(DEV)).sum().backward()
-    gt = 4e-5 if not bf16 else 6e-3
+    # bf16, observed: dx the reference's bits, keys / values 5e-8, w 2e-8 -- CVMM.backward's rounding points (cvmm.py:497-547) are
+    # followed by pretrain/cvmm.py since round 3 (4.4e-3 / 3.1e-3 / 2.2e-3 before, under a 6e-3 bound)
+    gt = 4e-5 if not bf16 else 1e-6
     for name, t in (("x", x), ("keys", keys), ("values", values), ("w", w)):
         assert rel_l2(t.grad, fx["grads"][name].to(DEV)) <= gt, (name, rel_l2(t.grad, fx["grads"][name].to(DEV)))
 

@@ -10,12 +10,12 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA"
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline $EXTRA > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
+python3 bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline $EXTRA > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o t -- $CMD > $OUT/bench_${TAG}_under_rocprof.json 2> $OUT/kt.err || exit 1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o t -- $CMD > /dev/null 2> $OUT/pf.err || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o t -- $CMD > /dev/null 2> $OUT/pw.err || exit 1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pm -o t -- $CMD > /dev/null 2> $OUT/pm.err || exit 1
+timeout -k 10 ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o t -- $CMD > $OUT/bench_${TAG}_under_rocprof.json 2> $OUT/kt.err || exit 1
+timeout -k 10 ${PROF_TIMEOUT:-400} rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o t -- $CMD > /dev/null 2> $OUT/pf.err || exit 1
+timeout -k 10 ${PROF_TIMEOUT:-400} rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pw -o t -- $CMD > /dev/null 2> $OUT/pw.err || exit 1
+timeout -k 10 ${PROF_TIMEOUT:-400} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pm -o t -- $CMD > /dev/null 2> $OUT/pm.err || exit 1
 cd $ROOT
 find $OUT -name "*.csv" | head -20
 python3 tools/summarize_profile.py $(find $OUT/kt -name "*kernel_trace.csv") $OUT/bench_${TAG}_per_launch.txt \
