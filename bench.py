@@ -464,7 +464,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel family (grouped expert GEMM): FLOPs per launch / mean launch duration
         gemm = {k: v for k, v in prof.items() if k.startswith("grouped_gemm") or k.startswith("grouped_wgrad") or k.startswith("dense_wgrad") or k == "gate_wgrad"
-                or k.startswith("dense_gemm_mxfp8")}
+                or k.startswith("dense_gemm")}
         detail = {}
         for k, v in prof.items():
             if k in gemm:
