@@ -48,9 +48,9 @@ SIGNATURES = {
     "csmoe_gate_select": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, C.c_float, _i, _p, _p, _p, _p, _p, _p]),
     "csmoe_dispatch_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "csmoe_dispatch_tokens": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
-    "csmoe_dispatch_rows_bwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p]),
+    "csmoe_dispatch_rows_bwd": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _p]),
     "csmoe_combine": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "csmoe_combine_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "csmoe_combine_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "csmoe_grouped_gemm": (_i, [_p, _l, _p, _i, _l, _p, _p, _i, _i, _i, _i, _p, _p, _p, _l, _i, _i, _i, _i, _p]),
     "csmoe_dense_gemm": (_i, [_p, _l, _p, _i, _l, _p, _i, _i, _i, _p, _p, _p, _l, _i, _i, _i, _i, _p]),
     "csmoe_grouped_wgrad": (_i, [_p, _l, _p, _l, _p, _i, _i, _i, _i, _p, _l, _i, _i, _i, _i, _p, _p]),

@@ -60,8 +60,8 @@ int k_gate_select(const void*, const void*, int, int, int, int, int, int, float,
 int k_dispatch_rows(const void*, const int32_t*, int, void*, int, int, int, hipStream_t);
 int k_dispatch_tokens(const void*, const int32_t*, int, void*, int, int, int, hipStream_t);
 int k_combine(const void*, const int32_t*, const int32_t*, const float*, const void*, const void*, void*, int, int, int, int, int,
-              hipStream_t);
-int k_combine_bwd(const void*, const void*, const int32_t*, const float*, void*, float*, int, int, int, int, hipStream_t);
+              hipStream_t, const void* pre);
+int k_combine_bwd(const void*, const void*, const int32_t*, const float*, void*, float*, int, int, int, int, int, hipStream_t);
 int k_colsum(const void*, int64_t, const int32_t*, int, int, int, void* const*, void*, int, int, hipStream_t);
 int k_softplus_mean(const void*, void*, int, int, int, int, int, hipStream_t);
 int k_pair_cosine(const void* y, float* tok_loss, int T, int K, int D, int dtype, hipStream_t st);
@@ -264,10 +264,12 @@ int csmoe_dispatch_tokens(const void* x, const int32_t* slot_of, int K, void* xs
 }
 
 int csmoe_dispatch_rows_bwd(const void* dxs, const int32_t* slot_of, int K, const void* add, void* dx, int T, int D, int dtype,
-                            csmoe_stream_t stream) {
+                            const int32_t* idx, const void* pre, csmoe_stream_t stream) {
   CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && K <= 64 && T >= 0 && D > 0, "dispatch_rows_bwd: bad arguments");
   CSMOE_CHECK_ARG(T == 0 || (dxs && slot_of && dx), "dispatch_rows_bwd: null pointer");
-  return k_combine(dxs, slot_of, nullptr, nullptr, nullptr, add, dx, T, K, D, dtype, CSMOE_COMBINE_DOT, (hipStream_t)stream);
+  CSMOE_CHECK_ARG(!pre || idx, "dispatch_rows_bwd: `pre` is the first addend of the sequential form, which needs idx");
+  // idx given: sequential accumulation in x.dtype, slots in DESCENDING expert order, starting from `pre` (internal mode 3)
+  return k_combine(dxs, slot_of, idx, nullptr, nullptr, add, dx, T, K, D, dtype, idx ? 3 : CSMOE_COMBINE_DOT, (hipStream_t)stream, pre);
 }
 
 int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias,
@@ -276,15 +278,15 @@ int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, con
   CSMOE_CHECK_ARG(mode >= 0 && mode <= 2, "combine: bad mode %d", mode);
   CSMOE_CHECK_ARG(T == 0 || (y && slot_of && w && out), "combine: null pointer");
   CSMOE_CHECK_ARG(T == 0 || mode == CSMOE_COMBINE_DOT || idx, "combine: idx required for the sequential rounding rule");
-  return k_combine(y, slot_of, idx, w, obias, residual, out, T, K, D, dtype, mode, (hipStream_t)stream);
+  return k_combine(y, slot_of, idx, w, obias, residual, out, T, K, D, dtype, mode, (hipStream_t)stream, nullptr);
 }
 
 int csmoe_combine_bwd(const void* dout, const void* y, const int32_t* perm, const int32_t* slot_of, const float* w, void* dy,
-                      float* dw, int T, int K, int D, int dtype, csmoe_stream_t stream) {
+                      float* dw, int T, int K, int D, int dtype, int round_products, csmoe_stream_t stream) {
   (void)perm;
   CSMOE_CHECK_ARG(dtype_ok(dtype) && K > 0 && T >= 0 && D > 0, "combine_bwd: bad arguments");
   CSMOE_CHECK_ARG(T == 0 || (dout && slot_of && dy), "combine_bwd: null pointer");
-  return k_combine_bwd(dout, y, slot_of, w, dy, dw, T, K, D, dtype, (hipStream_t)stream);
+  return k_combine_bwd(dout, y, slot_of, w, dy, dw, T, K, D, dtype, round_products, (hipStream_t)stream);
 }
 
 int csmoe_grouped_gemm(const void* A, int64_t lda, const void* const* b_ptrs, int b_layout, int64_t ldb,

@@ -76,8 +76,13 @@ __global__ void __launch_bounds__(256) router_select_bwd_kernel(const void* scor
       // competition step (competesmoe.py:253-255): `weights` is an x.dtype TENSOR taken from the affinities and used twice -- as the
       // numerator and in the K-sum -- so under bf16 it receives its own gradient rounded (the weighted sum's backward hands back a
       // bf16 tensor), then two bf16 gradients (quotient, sum), added in bf16; the result is scattered into d affinity.  fp32: no-ops.
+      // The denominator's gradient in autograd's own sequence for `self / other` (derivatives.yaml: -grad * ((self / other) / other),
+      // every op a bf16 tensor op), then the K-sum of `sum`'s backward rounded once: emulated on the CPU this reproduces torch's
+      // gradient bit for bit, where one rounding of the closed form -sum(dw v) / denom^2 was 4.2e-3 off it (and d affinity with it:
+      // tools/comp_grad_probe.py).
       const float dwr = round_dt(mydw, dtype);
-      const float ddr = round_dt(-wave_sum(dwr * myv) / (denom * denom), dtype);
+      const float q = round_dt(round_dt(myv / denom, dtype) / denom, dtype);
+      const float ddr = round_dt(wave_sum(round_dt(-dwr * q, dtype)), dtype);
       dv = round_dt(round_dt(dwr / denom, dtype) + ddr, dtype);
     }
     if (mode == CSMOE_SEL_SIGMOID) {
@@ -313,11 +318,13 @@ __global__ void __launch_bounds__(256) dispatch_tokens_reg_kernel(const char* x,
 // Combine  (moe.py:204 / cvmm.py:481-483) and the dispatch backward gather-sum (cvmm.py:544-545)
 // =====================================================================================================================
 
+constexpr int COMBINE_SEQ_DESC = 3;   // internal: CSMOE_COMBINE_SEQ with the slots visited in descending expert order (dispatch backward)
 // TO = type of the residual `add` and of `out`: T, or float with T = bf16 (the pretrain stack's fp32 residual stream under
 // bf16 autocast: the combine result is rounded to bf16 like the reference's cvmm output, then added to the fp32 residual in fp32)
 template <typename T, int VEC, typename TO = T>
 __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t* slot_of, const int32_t* idx, const float* w,
-                                                      const T* obias, const TO* add, TO* out, int Tn, int K, int D, int mode) {
+                                                      const T* obias, const TO* add, TO* out, int Tn, int K, int D, int mode,
+                                                      const T* pre) {
 #pragma clang fp contract(off)   // the sequential rule is "multiply, round, add, round": no FMA contraction
   constexpr bool O32 = !std::is_same<T, TO>::value;
   static_assert(!O32 || (std::is_same<TO, float>::value && VEC == 8), "mixed combine: bf16 rows, fp32 residual / output, 8-column chunks");
@@ -333,7 +340,14 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
       if (w) myw = w[(int64_t)t * K + lane];
       if (idx) mye = idx[(int64_t)t * K + lane];
     }
-    if (mode != CSMOE_COMBINE_DOT && idx) {
+    if (mode == COMBINE_SEQ_DESC && idx) {
+      // dispatch backward of the LLaVA stack: autograd runs the experts' backward nodes last-created first, i.e. in DESCENDING
+      // expert order, and adds each one's dx into the leaf's buffer in x.dtype
+      for (int j = 0; j < K; ++j) {
+        int ej = __shfl(mye, j, 64);
+        rank += (ej > mye || (ej == mye && j < lane)) ? 1 : 0;
+      }
+    } else if (mode != CSMOE_COMBINE_DOT && idx) {
       // experts in ascending index order (the reference loops `for i, expert in enumerate(self.experts)`)
       for (int j = 0; j < K; ++j) {
         int ej = __shfl(mye, j, 64);
@@ -349,6 +363,11 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
       float acc[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+      if (pre && live) {                // the chain starts from this row (a gradient stream that reached the leaf earlier)
+        const T* prow = pre + (int64_t)t * D + d0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = DT<T>::ld(prow + v);
+      }
       // the residual / extra addend of this chunk: one vector load issued ahead of the K gathers
       float addv[VEC];
 #pragma unroll
@@ -520,7 +539,7 @@ __global__ void __launch_bounds__(256) combine_k2_kernel(const bf16* y, const in
 // i.e. one rounding on load)
 template <typename T, int VEC, typename TG = T>
 __global__ void __launch_bounds__(256) combine_bwd_kernel(const TG* dout, const T* y, const int32_t* slot_of, const float* w, T* dy,
-                                                          float* dw, int Tn, int K, int D) {
+                                                          float* dw, int Tn, int K, int D, int round_prod) {
   constexpr bool G32 = !std::is_same<T, TG>::value;
   static_assert(!G32 || (std::is_same<TG, float>::value && VEC == 8), "mixed combine_bwd: fp32 gradient, bf16 rows, 8-column chunks");
   const int lane = threadIdx.x & 63;
@@ -570,13 +589,18 @@ __global__ void __launch_bounds__(256) combine_bwd_kernel(const TG* dout, const 
           DT<T>::st(dy + (int64_t)m * D + d0, gv[0] * wk);
         }
         if (y) {
+          if (round_prod) {        // the weights are a T-typed tensor upstream: `grad * out` is rounded element by element (moe.py:204)
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) dot = fmaf(gv[v], yv[v], dot);
+            for (int v = 0; v < VEC; ++v) dot += DT<T>::rnd(gv[v] * yv[v]);
+          } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) dot = fmaf(gv[v], yv[v], dot);
+          }
         }
       }
       if (y && dw) {
         dot = wave_sum(dot);
-        if (lane == 0) dw[flat] = dot;
+        if (lane == 0) dw[flat] = round_prod ? DT<T>::rnd(dot) : dot;
       }
     }
   }
@@ -1304,57 +1328,57 @@ int k_dispatch_tokens(const void* x, const int32_t* slot_of, int K, void* xs, in
 }
 
 int k_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias, const void* add,
-              void* out, int T, int K, int D, int dtype, int mode, hipStream_t st) {
+              void* out, int T, int K, int D, int dtype, int mode, hipStream_t st, const void* pre) {
   if (T == 0) return CSMOE_OK;
   dim3 grid(stride_grid(T)), block(256);
-  const bool al = (((uintptr_t)y | (uintptr_t)out | (uintptr_t)obias | (uintptr_t)add) & 15) == 0;
+  const bool al = (((uintptr_t)y | (uintptr_t)out | (uintptr_t)obias | (uintptr_t)add | (uintptr_t)pre) & 15) == 0;
   static const bool generic_only = getenv("CSMOE_COMBINE_GENERIC") != nullptr;       // A/B switch
   if (dtype == CSMOE_BF16) {
-    if (K == 2 && D % 512 == 0 && al && !generic_only)
+    if (K == 2 && D % 512 == 0 && al && !generic_only && !pre && mode != COMBINE_SEQ_DESC)
       hipLaunchKernelGGL((combine_k2_kernel<bf16>), grid, block, 0, st, (const bf16*)y, slot_of, idx, w, (const bf16*)obias,
                          (const bf16*)add, (bf16*)out, T, D, mode);
     else if (D % 8 == 0 && al)
       hipLaunchKernelGGL((combine_kernel<bf16, 8>), grid, block, 0, st, (const bf16*)y, slot_of, idx, w, (const bf16*)obias,
-                         (const bf16*)add, (bf16*)out, T, K, D, mode);
+                         (const bf16*)add, (bf16*)out, T, K, D, mode, (const bf16*)pre);
     else
       hipLaunchKernelGGL((combine_kernel<bf16, 1>), grid, block, 0, st, (const bf16*)y, slot_of, idx, w, (const bf16*)obias,
-                         (const bf16*)add, (bf16*)out, T, K, D, mode);
+                         (const bf16*)add, (bf16*)out, T, K, D, mode, (const bf16*)pre);
   } else {
     if (D % 4 == 0 && al)
       hipLaunchKernelGGL((combine_kernel<float, 4>), grid, block, 0, st, (const float*)y, slot_of, idx, w, (const float*)obias,
-                         (const float*)add, (float*)out, T, K, D, mode);
+                         (const float*)add, (float*)out, T, K, D, mode, (const float*)pre);
     else
       hipLaunchKernelGGL((combine_kernel<float, 1>), grid, block, 0, st, (const float*)y, slot_of, idx, w, (const float*)obias,
-                         (const float*)add, (float*)out, T, K, D, mode);
+                         (const float*)add, (float*)out, T, K, D, mode, (const float*)pre);
   }
   CSMOE_CHECK_LAUNCH("combine");
   return CSMOE_OK;
 }
 
 int k_combine_bwd(const void* dout, const void* y, const int32_t* perm, const float* w, void* dy, float* dw, int n, int K, int D,
-                  int dtype, hipStream_t st) {
+                  int dtype, int round_prod, hipStream_t st) {
   // `perm` here is slot_of (token-major traversal); n = T
   if (n == 0) return CSMOE_OK;
   dim3 grid(stride_grid(n)), block(256);
   const bool al = (((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0;
   static const bool generic_only = getenv("CSMOE_COMBINE_GENERIC") != nullptr;       // A/B switch
   if (dtype == CSMOE_BF16) {
-    if (K == 2 && D % 512 == 0 && al && !generic_only)
+    if (K == 2 && D % 512 == 0 && al && !generic_only && !round_prod)
       hipLaunchKernelGGL((combine_bwd_k2_kernel<bf16>), grid, block, 0, st, (const bf16*)dout, (const bf16*)y, perm, w, (bf16*)dy,
                          dw, n, D);
     else if (D % 8 == 0 && al)
       hipLaunchKernelGGL((combine_bwd_kernel<bf16, 8>), grid, block, 0, st, (const bf16*)dout, (const bf16*)y, perm, w, (bf16*)dy,
-                         dw, n, K, D);
+                         dw, n, K, D, round_prod);
     else
       hipLaunchKernelGGL((combine_bwd_kernel<bf16, 1>), grid, block, 0, st, (const bf16*)dout, (const bf16*)y, perm, w, (bf16*)dy,
-                         dw, n, K, D);
+                         dw, n, K, D, round_prod);
   } else {
     if (D % 4 == 0 && al)
       hipLaunchKernelGGL((combine_bwd_kernel<float, 4>), grid, block, 0, st, (const float*)dout, (const float*)y, perm, w,
-                         (float*)dy, dw, n, K, D);
+                         (float*)dy, dw, n, K, D, round_prod);
     else
       hipLaunchKernelGGL((combine_bwd_kernel<float, 1>), grid, block, 0, st, (const float*)dout, (const float*)y, perm, w,
-                         (float*)dy, dw, n, K, D);
+                         (float*)dy, dw, n, K, D, round_prod);
   }
   CSMOE_CHECK_LAUNCH("combine_bwd");
   return CSMOE_OK;
@@ -1370,7 +1394,7 @@ int k_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* idx, c
                        (const bf16*)nullptr, add, out, T, D, mode);
   else
     hipLaunchKernelGGL((combine_kernel<bf16, 8, float>), dim3(stride_grid(T)), dim3(256), 0, st, (const bf16*)y, slot_of, idx, w,
-                       (const bf16*)nullptr, add, out, T, K, D, mode);
+                       (const bf16*)nullptr, add, out, T, K, D, mode, (const bf16*)nullptr);
   CSMOE_CHECK_LAUNCH("combine_mixed");
   return CSMOE_OK;
 }
@@ -1384,7 +1408,7 @@ int k_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of
                        (bf16*)dy, dw, T, D);
   else
     hipLaunchKernelGGL((combine_bwd_kernel<bf16, 8, float>), dim3(stride_grid(T)), dim3(256), 0, st, dout, (const bf16*)y, slot_of, w,
-                       (bf16*)dy, dw, T, K, D);
+                       (bf16*)dy, dw, T, K, D, 0);
   CSMOE_CHECK_LAUNCH("combine_bwd_mixed");
   return CSMOE_OK;
 }

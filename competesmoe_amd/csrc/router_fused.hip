@@ -129,12 +129,15 @@ __global__ void __launch_bounds__(64 * RF_WAVES) gate_select_kernel(const bf16* 
       if (live && e < E) logits[(int64_t)t * E + e] = (bf16)s[j];
     }
     const int64_t tt = live ? t : 0;
+    int myi[4];
     select_row_g16(s, i16, E, K, mode, round_sum_bf16, sel_param, CSMOE_BF16, live, softmax ? softmax + tt * E : nullptr,
-                   idx + tt * K, w + tt * K);
+                   idx + tt * K, w + tt * K, myi);
     if (block_hist && live) {
+      // the ids this lane selected, from its registers: reading them back from `idx` put a store acknowledgement and a global load
+      // (~2 us) into each of the four passes of every wave -- the tail in which the E = 64 router lost its 4.9 TB/s
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (i16 + 16 * j < K) atomicAdd(&hist[idx[tt * K + i16 + 16 * j]], 1);     // this lane wrote that id
+        if (i16 + 16 * j < K) atomicAdd(&hist[myi[j]], 1);
     }
   }
   if (block_hist) {

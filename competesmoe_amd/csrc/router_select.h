@@ -129,8 +129,11 @@ __device__ __forceinline__ void g16_argmax(float& v, int& i) {
 }
 
 // s[j] = score of expert l16 + 16 j (-inf for experts >= E); `live` = this group's row exists (all lanes run the shuffles anyway)
+// `myi` (out): lane l16 holds in myi[j] the (l16 + 16 j)-th selected expert id (the value it writes to idx_row), so that a caller that
+// needs the ids again (the binning histogram of the one-pass router) does not read them back from global memory
 __device__ __forceinline__ void select_row_g16(const float (&s)[4], int l16, int E, int K, int mode, int round_sum_bf16,
-                                               float sel_param, int dtype, bool live, float* sm_row, int32_t* idx_row, float* w_row) {
+                                               float sel_param, int dtype, bool live, float* sm_row, int32_t* idx_row, float* w_row,
+                                               int (&myi)[4]) {
   float key[4], ex[4];
   float mx = g16_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
 #pragma unroll
@@ -148,7 +151,8 @@ __device__ __forceinline__ void select_row_g16(const float (&s)[4], int l16, int
   }
   float vsum = 0.f;
   float myv[4] = {0.f, 0.f, 0.f, 0.f};     // virtual lane k keeps the k-th value
-  int myi[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) myi[j] = 0;
   for (int k = 0; k < K; ++k) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -204,4 +208,9 @@ __device__ __forceinline__ void select_row_g16(const float (&s)[4], int l16, int
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (live && l16 + 16 * j < K) { w_row[l16 + 16 * j] = wk[j]; idx_row[l16 + 16 * j] = myi[j]; }
+}
+__device__ __forceinline__ void select_row_g16(const float (&s)[4], int l16, int E, int K, int mode, int round_sum_bf16,
+                                               float sel_param, int dtype, bool live, float* sm_row, int32_t* idx_row, float* w_row) {
+  int myi[4];
+  select_row_g16(s, l16, E, K, mode, round_sum_bf16, sel_param, dtype, live, sm_row, idx_row, w_row, myi);
 }

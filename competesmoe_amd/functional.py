@@ -365,7 +365,7 @@ def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residua
                                            want_c2=True, want_c=tab.act != L.ACT_RELU)
         y = ops.grouped_gemm_f32w(hact, values, bins.offsets, copy=v_copy)
         out = ops.combine(y, bins, idx, w, combine_mode, T, obias=obias, residual=residual)
-        return out, (bins, xs, hpre, hact, y)
+        return out, (bins, xs, hpre, hact, y, combine_mode, idx)
     ld1 = tab.D if tab.layout == L.B_NK else tab.F
     ld2 = tab.F if tab.layout == L.B_NK else tab.Dout
     # ReLU: act'(pre) = (act(pre) > 0), so the pre-activation is neither written (1.44 GB at the headline shape) nor re-read by the
@@ -377,7 +377,7 @@ def _ffn_forward(x2, w, idx, tab: ExpertTable, combine_mode: int, obias, residua
     y = ops.grouped_gemm(hact, tab.w2_ptrs, tab.layout, ld2, tab.Dout, bins.offsets, tab.E, bias_ptrs=tab.b2_ptrs,
                          epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
     out = ops.combine(y, bins, idx, w, combine_mode, T, obias=obias, residual=residual)
-    return out, (bins, xs, hpre, hact, y)
+    return out, (bins, xs, hpre, hact, y, combine_mode, idx)
 
 
 _WGRAD_SPLIT = os.environ.get("CSMOE_WGRAD_SPLIT", "1") != "0"       # A/B switch
@@ -403,15 +403,47 @@ def _grouped_wgrad(a: torch.Tensor, b: torch.Tensor, bins, E: int, pd) -> torch.
     return ops.sum_partials(part.view(E * P, Na * Nb), E, P, pd).view(E, Na, Nb)
 
 
-def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool, dy_extra=None, dx_add=None):
+class DxHandoff:
+    """Carries the always-on expert's dx (DenseFFN.backward) to the routed step's gather-sum (MoEFFNModules.backward) of the SAME layer
+    call, where it enters as the chain's first addend (csmoe_dispatch_rows_bwd `pre`): the reference's autograd adds the streams of x
+    one expert at a time in x.dtype -- shared expert (created last, so its node runs first), routed experts E-1 .. 0, gate -- and the
+    shared-expert fixtures' dx is exactly that chain (tests/test_llava_modules_gpu.py).  Summing the routed experts first and adding
+    the shared stream afterwards, as two autograd nodes do, is 2.8e-3 away from it.  The engine runs the later-created node first; if
+    it ever did not, both nodes fall back to plain accumulation (`routed_done`)."""
+    __slots__ = ("dx", "routed_done", "has_consumer")
+
+    def __init__(self):
+        self.dx, self.routed_done, self.has_consumer = None, False, False
+
+
+_PENDING_HANDOFF = None        # set by a shared-expert layer around its two calls, taken by the forward of the node it is meant for
+
+
+def set_handoff(h):
+    global _PENDING_HANDOFF
+    _PENDING_HANDOFF = h
+
+
+def _take_handoff():
+    global _PENDING_HANDOFF
+    h, _PENDING_HANDOFF = _PENDING_HANDOFF, None
+    return h
+
+
+def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool, need_params: bool, dy_extra=None, dx_add=None,
+                  handoff=None):
     """Returns dx2, dw, (gW1 [E,..], gb1 [E,F]|None, gW2 [E,..], gb2 [E,Dout]|None).
     `dx_add`: a callable dw -> [T, D] tensor (or None) added to dx INSIDE the gather-sum of the binned rows (csmoe_dispatch_rows_bwd's
-    `add` input): the gate-path gradient of x, which depends on this function's dw (SparseMoEModules)."""
+    `add` input): the gate-path gradient of x, which depends on this function's dw (SparseMoEModules).
+    `handoff`: DxHandoff of a shared-expert layer (its always-on expert's dx becomes the chain's first addend)."""
     if saved is None:
         raise RuntimeError("competesmoe_amd: the MoE layer's saved activations were freed by the first backward pass "
                            "(they are released early to bound memory); a second backward through the same graph "
                            "(retain_graph=True) is not supported -- run the forward again")
-    bins, xs, hpre, hact, y = saved
+    bins, xs, hpre, hact, y, *rest = saved
+    # competition steps hand in bf16 routing weights (COMBINE_SEQ_RW): the reference's `weights * out_exp` is then a bf16 product and
+    # its autograd forms d w = (grad * out).sum(-1) with every product rounded to bf16 and the sum rounded once (moe.py:204)
+    round_dw = bool(rest) and rest[0] == L.COMBINE_SEQ_RW
     T = dout.shape[0]
     dev = dout.device
     E = tab.E
@@ -423,7 +455,7 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
     if scale_after and need_dw and hpre is None:
         dot_cols = ops.rowdot_cols(bins.n, tab.F, tab.Dout, tab.Dout, ld2, tab.F, hact.dtype)
     dy, dw = ops.combine_bwd(dout.contiguous(), y if (need_dw and not dot_cols) else None, bins, w, want_dw=need_dw and not dot_cols,
-                             act_dtype=hact.dtype)
+                             act_dtype=hact.dtype, round_products=round_dw)
     if dy_extra is not None:                # gradient of the per-slot outputs (MoEFFNModulesSlots), already in binned order
         dy = dy + dy_extra
     ld1 = tab.D if tab.layout == L.B_NK else tab.F
@@ -467,7 +499,22 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
     dx2 = None
     if need_dx:
         dxs = ops.grouped_gemm(dh, tab.w1_ptrs, _flip(tab.layout), ld1, tab.D, bins.offsets, E)
-        dx2 = ops.dispatch_rows_bwd(dxs, bins, T, add=None if dx_add is None else dx_add(dw))
+        pre = None
+        if handoff is not None:
+            pre, handoff.dx, handoff.routed_done = handoff.dx, None, True
+        # the LLaVA stack's per-expert modules: sequential x.dtype accumulation in descending expert order (for K <= 2 without a
+        # first addend that IS round(sum), so the fast gather-sum stays); the pretrain stack's cvmm reduces over K in fp32
+        seq_idx = rest[1] if (len(rest) > 1 and rest[0] != L.COMBINE_DOT and (pre is not None or bins.K > 2)) else None
+        if pre is not None and seq_idx is None:        # cannot happen for the LLaVA layers; keep the stream
+            pre_lost, pre = pre, None
+        else:
+            pre_lost = None
+        dx2 = ops.dispatch_rows_bwd(dxs, bins, T, add=None if dx_add is None else dx_add(dw),
+                                    idx=None if seq_idx is None else seq_idx.contiguous(), pre=pre)
+        if pre_lost is not None:
+            dx2 = dx2 + pre_lost
+    elif handoff is not None:
+        handoff.routed_done = True
     return dx2, dw, grads
 
 
@@ -484,6 +531,9 @@ class MoEFFNModules(torch.autograd.Function):
         out, saved = _ffn_forward(x2, w, idx, tab, combine_mode, None)
         ctx.tab, ctx.saved, ctx.w = tab, saved, w
         ctx.n_params = len(params)
+        ctx.handoff = _take_handoff()
+        if ctx.handoff is not None:
+            ctx.handoff.has_consumer = True          # without a routed node that will take it, the always-on expert keeps its dx
         return out
 
     @staticmethod
@@ -491,7 +541,7 @@ class MoEFFNModules(torch.autograd.Function):
         tab = ctx.tab
         need_params = any(ctx.needs_input_grad[5:])
         dx2, dw, grads = _ffn_backward(dout, ctx.w, tab, ctx.saved, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                       need_params)
+                                       need_params, handoff=ctx.handoff)
         ctx.saved = None
         pg: List[Optional[torch.Tensor]] = [None] * ctx.n_params
         if grads is not None:
@@ -823,6 +873,7 @@ class DenseFFN(torch.autograd.Function):
         y = ops.dense_gemm(hact, w2o, layout, bias=b2o, epilogue=L.EPI_BIAS if b2o is not None else L.EPI_PLAIN)
         ctx.save_for_backward(x2, w1o, w2o, hpre, hact)
         ctx.cfg = (act, layout, w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
+        ctx.handoff = _take_handoff()
         return y
 
     @staticmethod
@@ -842,6 +893,11 @@ class DenseFFN(torch.autograd.Function):
             gb1 = _chunked_dense_colsum(dh, dt_b1)
         if ctx.needs_input_grad[0]:
             dx = ops.dense_gemm(dh, w1o, _flip(layout))
+            h = ctx.handoff
+            if h is not None and h.has_consumer and not h.routed_done:
+                # the always-on expert of a shared-expert layer: its dx is the FIRST addend of the routed step's chain (DxHandoff);
+                # this node hands nothing to the engine (None = zero)
+                h.dx, dx = dx, None
         return dx, gw1, gb1, gw2, gb2, None, None
 
 

@@ -5,8 +5,11 @@ import copy
 
 import torch.nn as nn
 
+import torch
+
 from .register import register_moe
 from .moe import MoeLayer
+from ..functional import DxHandoff, set_handoff
 
 
 class _SharedBase(MoeLayer):
@@ -26,8 +29,17 @@ class _SharedBase(MoeLayer):
     def _routed_and_shared(self, x):
         """(routed output over the E-1 gated experts, dense output of the always-on last expert, the routing record)."""
         route = self._route(x)
-        routed = self.compute_moe(route.idx, route.w, None, x, n_experts=self.num_of_experts)
-        return routed, self.dense_expert(self.num_of_experts, x), route
+        # bf16 training: the always-on expert's dx joins the routed experts' gather-sum as its first addend, which is the order the
+        # reference's autograd accumulates x's gradient streams in (functional.DxHandoff)
+        h = DxHandoff() if (x.requires_grad and torch.is_grad_enabled() and x.dtype != torch.float32) else None
+        try:
+            set_handoff(h)
+            routed = self.compute_moe(route.idx, route.w, None, x, n_experts=self.num_of_experts)
+            set_handoff(h)
+            shared = self.dense_expert(self.num_of_experts, x)
+        finally:
+            set_handoff(None)
+        return routed, shared, route
 
 
 @register_moe("smoe_share")

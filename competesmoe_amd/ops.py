@@ -339,12 +339,16 @@ def dispatch_tokens(x2: torch.Tensor, bins: Bins) -> torch.Tensor:
     return xs
 
 
-def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None,
+                      pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx[t] = round(round(sum_k dxs[slot]) + add[t]); with `idx` [T, K] (int32) the sequential form of the LLaVA stack's autograd:
+    (((pre[t] + dxs[slot of the highest expert]) + ...) + dxs[slot of the lowest]) + add[t], rounded after every add (csmoe.h)."""
     D = dxs.shape[1]
     dx = torch.empty(T, D, dtype=dxs.dtype, device=dxs.device)
-    with _timed("dispatch_rows_bwd", (T * (2 if add is not None else 1) + bins.n) * D * dxs.element_size()):     # `add` is one more [T, D] read
+    streams = 1 + (add is not None) + (pre is not None)
+    with _timed("dispatch_rows_bwd", (T * streams + bins.n) * D * dxs.element_size()):     # `add` / `pre` are [T, D] reads
         L.check(lib.csmoe_dispatch_rows_bwd(dxs.data_ptr(), bins.slot_of.data_ptr(), bins.K, _ptr(add), dx.data_ptr(), T, D,
-                                            _dt(dxs), _stream()), "dispatch_rows_bwd")
+                                            _dt(dxs), _ptr(idx), _ptr(pre), _stream()), "dispatch_rows_bwd")
     return dx
 
 
@@ -443,8 +447,11 @@ def layernorm_bwd(dxn: torch.Tensor, x2: torch.Tensor, gamma: Optional[torch.Ten
     return dx, sums[:D], sums[D:]
 
 
-def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: torch.Tensor, want_dw: bool = True, act_dtype=None):
-    """`act_dtype` = dtype of the expert rows when it differs from dout's (fp32 upstream gradient, bf16 rows)."""
+def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: torch.Tensor, want_dw: bool = True, act_dtype=None,
+                round_products: bool = False):
+    """`act_dtype` = dtype of the expert rows when it differs from dout's (fp32 upstream gradient, bf16 rows).
+    `round_products`: d w as autograd forms it when the weights are an x.dtype tensor (competition steps): every product
+    dout * y rounded to the dtype, the sum rounded once."""
     T, D = dout.shape
     if act_dtype == torch.bfloat16 and dout.dtype == torch.float32:
         dy = torch.empty(bins.n, D, dtype=torch.bfloat16, device=dout.device)
@@ -457,7 +464,7 @@ def combine_bwd(dout: torch.Tensor, y: Optional[torch.Tensor], bins: Bins, w: to
     dw = torch.empty(T, bins.K, dtype=torch.float32, device=dout.device) if (want_dw and y is not None) else None
     with _timed("combine_bwd", (T + bins.n * (2 if y is not None else 1)) * D * dout.element_size()):
         L.check(lib.csmoe_combine_bwd(dout.data_ptr(), _ptr(y), bins.perm.data_ptr(), bins.slot_of.data_ptr(), w.data_ptr(),
-                                      dy.data_ptr(), _ptr(dw), T, bins.K, D, _dt(dout), _stream()), "combine_bwd")
+                                      dy.data_ptr(), _ptr(dw), T, bins.K, D, _dt(dout), int(round_products), _stream()), "combine_bwd")
     return dy, dw
 
 

@@ -160,9 +160,15 @@ int csmoe_dispatch_rows(const void* x, const int32_t* perm, int K, void* xs, int
 /* token-major dispatch (same result; reads every x row from HBM once): xs[slot_of[t*K+k], :] = x[t, :] */
 int csmoe_dispatch_tokens(const void* x, const int32_t* slot_of, int K, void* xs, int T, int D, int dtype,
                           csmoe_stream_t stream);
-/* dispatch backward: dx[t,:] = sum_k dxs[slot_of[t*K+k], :] (+ add[t,:] if add != null)   (cvmm.py:544-545) */
+/* dispatch backward: dx[t,:] = round(round(sum_k dxs[slot_of[t*K+k], :]) + add[t,:])  (add may be null): the K-sum in fp32, rounded
+ * once -- CVMM.backward's reduction (cvmm.py:544-545) and, for K <= 2, the LLaVA stack's autograd.
+ * `idx` [T,K] != null selects what autograd does for the LLaVA stack's per-expert modules (moe.py:196-204): every expert's `x[...]`
+ * is its own use of x, the engine runs their backward nodes last-created first and adds each result into the leaf's buffer in
+ * x.dtype -- dx[t] = (((pre[t] + dxs[slot of the HIGHEST expert]) + ...) + dxs[slot of the lowest]) + add[t], rounded after every
+ * add.  `pre` [T,D] (may be null) = a gradient stream that reached x before the experts' (the always-on expert of smoe_share /
+ * deepseekv3, shard_smoe.py:53, created after the routed experts); `add` = one that arrives after them (the gate's). */
 int csmoe_dispatch_rows_bwd(const void* dxs, const int32_t* slot_of, int K, const void* add, void* dx, int T, int D,
-                            int dtype, csmoe_stream_t stream);
+                            int dtype, const int32_t* idx, const void* pre, csmoe_stream_t stream);
 /* combine: out[t,:] = sum_k w[t,k] * y[slot_of[t*K+k], :]  (+ obias[:] if non-null) with the rounding rule `mode`
  * (moe.py:204; cvmm.py:481-483).  idx gives the expert of each slot (visit order for COMBINE_SEQ).
  * `residual` [T,D] (may be null) is added last, as one more x.dtype addition: out = round(out + residual) -- the
@@ -170,9 +176,12 @@ int csmoe_dispatch_rows_bwd(const void* dxs, const int32_t* slot_of, int K, cons
 int csmoe_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const float* w, const void* obias,
                   const void* residual, void* out, int T, int K, int D, int dtype, int mode, csmoe_stream_t stream);
 /* combine backward: dy[m,:] = round(w * dout[t,:]) in the binned row space; dw[t,k] = <dout[t,:], y[slot,:]>
- * (y may be null -> dw not written).  (autograd of moe.py:204; cvmm.py:497-499,543) */
+ * (y may be null -> dw not written).  (autograd of moe.py:204; cvmm.py:497-499,543)
+ * `round_products` != 0: dw[t,k] = round(sum_d round(dout[t,d] * y[slot,d])), every product and the sum rounded to `dtype` -- what
+ * autograd returns for `weights * out_exp` when the weights are an x.dtype tensor (the competition step's affinity weights,
+ * competesmoe.py:253-258 -> moe.py:204); 0: one fp32 dot product (fp32 weights: router steps, cvmm). */
 int csmoe_combine_bwd(const void* dout, const void* y, const int32_t* perm, const int32_t* slot_of, const float* w,
-                      void* dy, float* dw, int T, int K, int D, int dtype, csmoe_stream_t stream);
+                      void* dy, float* dw, int T, int K, int D, int dtype, int round_products, csmoe_stream_t stream);
 
 /* ---- grouped expert GEMM -----------------------------------------------------------------------------
  * Row-space GEMM: for every expert e and binned row m in [offsets[e], offsets[e+1]):
