@@ -145,13 +145,16 @@ __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_pt
   const int t = threadIdx.x;
   const int rt_n = (R + QB_R - 1) / QB_R, cb_n = (C + QB_C - 1) / QB_C, nbc = C >> 5, nbr = R >> 5;
   const int64_t tiles = (int64_t)rt_n * cb_n;
-  for (int64_t ti = blockIdx.x; ti < tiles; ti += gridDim.x) {
+  // A tile's eight 16-byte loads per thread are all issued into registers before the first LDS write (round 3: 4.2 -> 4.5 TB/s; written
+  // as load-then-store per row, hipcc waited for each load in turn).  When a workgroup has more than one tile (grids beyond 16 384
+  // tiles per expert) the next tile's loads are issued before the current one is quantised.
+  f32x4 nxt[8];
+  auto fetch = [&](int64_t ti) {
     const int rt = (int)(ti / cb_n), cb = (int)(ti - (int64_t)rt * cb_n);
     const int r0 = rt * QB_R, c0 = cb * QB_C;
-    // ---- load: thread -> (row t / 32 + 8 i, 4 columns (t % 32) * 4), 8 rows per thread
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int r = (t >> 5) + 8 * i, c = (t & 31) * 4;
+      const int r = (t >> 5) + 8 * i, c = (t & 31) * 4;      // thread -> (row t / 32 + 8 i, 4 columns (t % 32) * 4)
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (c0 + c < C && r0 + r < R) {
         const T* src = x + (int64_t)(r0 + r) * ldx + c0 + c;
@@ -162,9 +165,17 @@ __global__ void __launch_bounds__(256) quant_both_kernel(const void* const* x_pt
           v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
         }
       }
-      *(f32x4*)(tile + r * QB_LD + c) = v;
+      nxt[i] = v;
     }
+  };
+  if ((int64_t)blockIdx.x < tiles) fetch(blockIdx.x);
+  for (int64_t ti = blockIdx.x; ti < tiles; ti += gridDim.x) {
+    const int rt = (int)(ti / cb_n), cb = (int)(ti - (int64_t)rt * cb_n);
+    const int r0 = rt * QB_R, c0 = cb * QB_C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(f32x4*)(tile + ((t >> 5) + 8 * i) * QB_LD + (t & 31) * 4) = nxt[i];
     __syncthreads();
+    if (ti + gridDim.x < tiles) fetch(ti + gridDim.x);
     {
       // ---- row-major output: unit (row t / 4, column block t % 4)
       const int r = t >> 2, bk = t & 3;
@@ -223,6 +234,8 @@ int k_quantize_mxfp8_both(const void* const* x_ptrs, const void* x_single, int E
                           void* s, void* qt, void* st, hipStream_t stream) {
   if (E <= 0 || R <= 0 || C <= 0) return CSMOE_OK;
   const int64_t tiles = (int64_t)((R + QB_R - 1) / QB_R) * ((C + QB_C - 1) / QB_C);
+  // one tile per workgroup where the grid allows (16 384 per expert): a persistent grid walking several tiles per workgroup with
+  // the next tile prefetched measured SLOWER (2 048 workgroups 4.86 ms, 65 536 4.33 ms, one per tile 3.92 ms per 128-expert table)
   dim3 grid((unsigned)std::min<int64_t>(tiles, 16384), (unsigned)E), block(256);
   const int64_t q_mat = (int64_t)R * C, s_mat = (int64_t)R * (C / 32), st_mat = (int64_t)C * (R / 32);
   if (in_dtype == CSMOE_BF16)
