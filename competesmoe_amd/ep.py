@@ -186,6 +186,7 @@ class EPFFN(torch.autograd.Function):
         ctx.saved = (bins, lb, plan, rs, hpre, hact, y)
         ctx.tab, ctx.w, ctx.group, ctx.n_params = tab, w, group, len(params)
         ctx.want_slots = want_slots
+        ctx.round_dw = combine_mode == L.COMBINE_SEQ_RW        # bf16 affinity weights: d w as autograd forms it (functional._ffn_backward)
         y_tk = ops.dispatch_rows(y, _Unsort(bins)) if want_slots else y.new_empty(0)      # y_tk[t*K+k] = y[slot_of[t*K+k]]
         return out, y_tk
 
@@ -200,7 +201,7 @@ class EPFFN(torch.autograd.Function):
         assert tab.layout == L.B_NK
         E, dev, pd = tab.E, dout.device, tab.param_dtype
         T = dout.shape[0]
-        dy, dw = ops.combine_bwd(dout.contiguous(), y, bins, ctx.w, want_dw=ctx.needs_input_grad[1])
+        dy, dw = ops.combine_bwd(dout.contiguous(), y, bins, ctx.w, want_dw=ctx.needs_input_grad[1], round_products=ctx.round_dw)
         if dy_tk is not None and ctx.want_slots:               # gradient of the per-slot outputs (diversity loss), binned order
             dy = dy + ops.dispatch_rows(dy_tk.contiguous(), ops.Bins(None, None, bins.perm, None, bins.n, bins.E, 1))
         dys = ops.dispatch_rows(a2a_rows(dy, plan.send_splits, plan.recv_splits, group), lb)
