@@ -89,6 +89,24 @@ def test_ep_exchange_two_ranks_gloo(T, D, E, K):
     assert res == {0: True, 1: True}
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_ep_exchange_at_the_node_sizes_of_the_scaling_run_gloo(world):
+    """The same plumbing at 4 and 8 ranks (the sizes the driver's scaling run uses; no 8-GPU node is available to the build): plan,
+    variable-size exchange, chunked per-peer views, every rank's counts lining up -- with 2 local experts per rank at 8 ranks and an
+    expert nobody selects."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 96, 8, 16, 2, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert res == {r: True for r in range(world)}
+
+
 def _grad_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -221,6 +221,15 @@ def test_ep_chunked_world2_one_gpu_equals_single_gpu(dt_name, chunks):
     assert _launch(2, "gloo", dt_name, chunks) == {0: True, 1: True}
 
 
+@pytest.mark.parametrize("dt_name,chunks", [("bf16", 1), ("bf16", 2), ("fp32", 2)])
+def test_ep_world4_one_gpu_equals_single_gpu(dt_name, chunks):
+    """Four ranks (two local experts each) on the one GPU, collectives through gloo: the layer's full forward + backward with the
+    HIP kernels at a world size beyond 2 -- outputs and dx bit-identical to the single-GPU layer, expert gradients equal to the
+    all-reduced single-GPU ones, replicated gate gradient summed over the ranks.  (More ranks than this on one card are not allowed
+    on the test box; the exchange plumbing alone runs at 8 ranks in tests/test_ep_gloo.py.)"""
+    assert _launch(4, "gloo", dt_name, chunks) == {r: True for r in range(4)}
+
+
 @pytest.mark.parametrize("world,backend,chunks", [(1, "nccl", 1), (1, "nccl", 2), (2, "gloo", 1), (2, "gloo", 2)])
 def test_ep_with_experts_that_receive_nothing(world, backend, chunks):
     """Half of the experts are never selected: empty groups of the overlapped exchange, zero-row grouped GEMMs, and (world 2) a
