@@ -150,6 +150,10 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // tile's position.  Lane l handles expert l (+64, +128, ...): one batch of offset loads and a 6-step shuffle scan replace a
 // serial walk over E dependent scalar loads per workgroup.  Tiles are ordered (expert, column tile, row tile), row tile fastest.
 // Returns false when v is past the last tile.  All results are wave-uniform (broadcast from the owning lane).
+#ifndef CSMOE_TILE_BAND
+#define CSMOE_TILE_BAND 4
+#endif
+constexpr int TILE_BAND = CSMOE_TILE_BAND;      // row tiles per band of the row-space tile order (grouped_find_tile)
 struct TilePos { int e, o0, o1, mt, nt; };
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -192,8 +196,14 @@ __device__ __forceinline__ bool grouped_find_tile(const int32_t* offsets, int E,
       out.e = base + src;
       out.o0 = __shfl(o0, src, 64);
       out.o1 = __shfl(o1, src, 64);
-      out.mt = local % mte + (part == 2 ? 1 : 0);
-      out.nt = local / mte;
+      // row tiles in bands of TILE_BAND, column tiles inside a band, row tiles of the band fastest: the ~32 tiles an XCD's CUs hold at
+      // a time are then a 4 x 8 block sharing 4 row panels and 8 weight panels.  With at most TILE_BAND row tiles per expert (the
+      // headline: ~4) this IS the plain (n-tile, m-tile) order; with many (a dense always-on expert: 128 row tiles) the plain order
+      // made 32 concurrent tiles share ONE weight panel and stream 32 row panels.
+      const int band = local / (TILE_BAND * nct), rem = local - band * TILE_BAND * nct;
+      const int g_eff = min(TILE_BAND, mte - band * TILE_BAND);
+      out.mt = band * TILE_BAND + rem % g_eff + (part == 2 ? 1 : 0);
+      out.nt = rem / g_eff;
       return true;
     }
     acc = __shfl(incl, 63, 64);

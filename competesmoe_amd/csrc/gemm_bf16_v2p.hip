@@ -88,8 +88,16 @@ __device__ __forceinline__ TileW tile_of(const FastArgs& p, int v, int nct, int 
   t.e = __builtin_amdgcn_readfirstlane(e);
   t.row0 = __builtin_amdgcn_readfirstlane(row0);
   t.red_len = __builtin_amdgcn_readfirstlane(red_len);
-  t.tr0 = __builtin_amdgcn_readfirstlane((local / nct) * BM2);
-  t.tc0 = __builtin_amdgcn_readfirstlane((local % nct) * BN2);
+  // Tiles of an expert in bands of WG_BAND row tiles, column-major inside a band: the ~32 workgroups of an XCD hold consecutive
+  // positions of this order, i.e. a WG_BAND x 8 block of tiles that shares WG_BAND row panels and 8 column panels (12 panels of
+  // 256 x red_len for 32 tiles) where the row-major order had them share ONE row panel and fetch 32 column panels.
+  // CSMOE_WGRAD_BAND=1 (A/B) is the row-major order.
+  const int band = p.tile_band > 0 ? p.tile_band : 1;
+  const int nrt = per_e / nct;
+  const int grp = local / (band * nct), rem = local - grp * band * nct;
+  const int g_eff = min(band, nrt - grp * band);
+  t.tr0 = __builtin_amdgcn_readfirstlane((grp * band + rem % g_eff) * BM2);
+  t.tc0 = __builtin_amdgcn_readfirstlane((rem / g_eff) * BN2);
   return t;
 }
 
@@ -589,6 +597,8 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
   p.single_M = single_M; p.single_C = single_C;
   p.R = A; p.ld_r = lda; p.Cflat = B; p.ld_c = ldb; p.offsets = offsets; p.E = E; p.NR = Na; p.NC = Nb;
   p.out_ptrs = c_ptrs; p.ldc = ldc; p.accumulate = accumulate; p.out_f32 = (out_dtype == CSMOE_F32);
+  static const int band = [] { const char* e = getenv("CSMOE_WGRAD_BAND"); return e ? atoi(e) : 4; }();
+  p.tile_band = band;
   int64_t grid = (int64_t)E * ((Na + BM2 - 1) / BM2) * ((Nb + BN2 - 1) / BN2);
   // the dealt order needs the persistent grid to be a multiple of 8 (workgroup id % 8 = XCD)
   p.xcd_order = (offsets && xcd_order && persistent_grid(grid) % 8 == 0 && persistent_grid(grid) < grid) ? xcd_order : nullptr;

@@ -28,6 +28,7 @@ struct FastArgs {
   void* const* out_ptrs;                      // wgrad outputs
   int epilogue, act, accumulate, out_f32;
   const int32_t* xcd_order;                   // persistent wgrad: experts dealt to XCDs (csmoe_expert_order), or null
+  int tile_band;                              // persistent weight gradient: row tiles per band of the tile order (gemm_bf16_v2p.hip tile_of)
   int row_part;                               // row-space v2: which row tiles of every expert (common.h part_tiles)
   int thin_loop;                              // row-space v2: tiles of <= 128 rows take the one-phase loop
 };
