@@ -18,6 +18,9 @@
 
 namespace {
 
+#ifndef CSMOE_RF_DIAG
+#define CSMOE_RF_DIAG 0      // 1: no selection phase; 2: no gate staging (the first chunk's gate tile is reused for every chunk)
+#endif
 #ifndef CSMOE_RF_WAVES
 #define CSMOE_RF_WAVES 4
 #endif
@@ -26,12 +29,19 @@ constexpr int RF_ROWS = 16 * RF_WAVES;     // token rows per workgroup
 constexpr int RF_KCH = 256;           // K-chunk staged in LDS
 constexpr int RF_LD = RF_KCH + 8;     // bf16 elements per staged gate row (528 B)
 
-template <int NE>                     // NE = ceil(E / 16) column blocks
+// NE = ceil(E / 16) column blocks.  SPEC: the selection rule and K are compile-time constants (softmax top-2 with the bf16-rounded K-sum:
+// `smoe`'s, the headline's) -- the four row passes of a wave then are straight-line code the scheduler interleaves; with run-time
+// `mode` / `K` every pass is a chain of ~600 dependent instructions behind uniform branches, two waves per SIMD to hide it
+// (tools/router_diag.py: 21 us of selection behind a 52 us stream at E = 64).
+template <int NE, bool SPEC = false>
 __global__ void __launch_bounds__(64 * RF_WAVES) gate_select_kernel(const bf16* __restrict__ x, const bf16* __restrict__ wg, int T, int D, int E,
-                                                          int K, int mode, int round_sum_bf16, float sel_param,
+                                                          int K_rt, int mode_rt, int round_sum_rt, float sel_param,
                                                           bf16* __restrict__ logits, float* __restrict__ softmax,
                                                           int32_t* __restrict__ idx, float* __restrict__ w,
                                                           int32_t* __restrict__ block_hist) {
+  const int K = SPEC ? 2 : K_rt;
+  const int mode = SPEC ? (int)CSMOE_SEL_SOFTMAX : mode_rt;
+  const int round_sum_bf16 = SPEC ? 1 : round_sum_rt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* wbuf = (bf16*)smem;                                   // 2 x [NE*16][RF_LD]
   constexpr int WB = NE * 16 * RF_LD;                         // elements per buffer
@@ -72,10 +82,10 @@ __global__ void __launch_bounds__(64 * RF_WAVES) gate_select_kernel(const bf16* 
   };
   // one chunk: fetch the gate chunk ch+1 and the x chunk ch+2, multiply chunk ch, publish gate chunk ch+1
   auto step = [&](int ch, bf16x8 (&a_use)[8], bf16x8 (&a_fill)[8]) {
-    const bool more = ch + 1 < nch;
+    const bool more = (CSMOE_RF_DIAG == 2) ? false : ch + 1 < nch;
     if (more) load_w(ch + 1);
     if (ch + 2 < nch) load_a(a_fill, ch + 2);
-    const bf16* wb = wbuf + (ch & 1) * WB + i16 * RF_LD + 8 * g;
+    const bf16* wb = wbuf + ((CSMOE_RF_DIAG == 2) ? 0 : (ch & 1)) * WB + i16 * RF_LD + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
@@ -103,6 +113,10 @@ __global__ void __launch_bounds__(64 * RF_WAVES) gate_select_kernel(const bf16* 
     if (ch + 2 < nch) step(ch + 2, a[2], a[1]);
   }
 
+#if CSMOE_RF_DIAG == 1      // timing experiment (wrong results): the stream + MFMA loop alone, no selection
+  if (acc[0][0] == 1.2345e30f) logits[0] = (bf16)acc[0][0];
+  return;
+#endif
   // ---- logits of this wave's 16 rows -> LDS (fp32 value of the bf16-rounded logit), then row by row through the selection routine
   float* lrow = (float*)smem + wave * 16 * 65;                 // [16][65] per wave, over the gate buffers (all reads are done)
 #pragma unroll
@@ -117,6 +131,7 @@ __global__ void __launch_bounds__(64 * RF_WAVES) gate_select_kernel(const bf16* 
     __syncthreads();
   }
   // four rows per pass, sixteen lanes per row (select_row_g16: the bits of the wave-per-row routine)
+#pragma unroll
   for (int r4 = 0; r4 < 4; ++r4) {
     const int r = r4 * 4 + g;
     const int t = row0 + r;
@@ -161,9 +176,14 @@ int k_gate_select(const void* x, const void* wg, int T, int D, int E, int K, int
   const int ne = (E + 15) / 16;
   const dim3 grid(k_gate_select_blocks(T)), block(64 * RF_WAVES);
   const size_t lds = std::max<size_t>((size_t)2 * ne * 16 * RF_LD * 2, (size_t)RF_WAVES * 16 * 65 * 4 + 256);
+  const bool spec = K == 2 && mode == CSMOE_SEL_SOFTMAX && round_sum_bf16;
 #define GS_LAUNCH(NE)                                                                                                    \
-  hipLaunchKernelGGL((gate_select_kernel<NE>), grid, block, lds, st, (const bf16*)x, (const bf16*)wg, T, D, E, K, mode,  \
-                     round_sum_bf16, sel_param, (bf16*)logits, softmax, idx, w, block_hist)
+  if (spec)                                                                                                              \
+    hipLaunchKernelGGL((gate_select_kernel<NE, true>), grid, block, lds, st, (const bf16*)x, (const bf16*)wg, T, D, E, K, mode,  \
+                       round_sum_bf16, sel_param, (bf16*)logits, softmax, idx, w, block_hist);                           \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((gate_select_kernel<NE, false>), grid, block, lds, st, (const bf16*)x, (const bf16*)wg, T, D, E, K, mode,  \
+                       round_sum_bf16, sel_param, (bf16*)logits, softmax, idx, w, block_hist)
   switch (ne) {
     case 1: GS_LAUNCH(1); break;
     case 2: GS_LAUNCH(2); break;

@@ -108,24 +108,34 @@ __device__ __forceinline__ void select_row(const float (&s)[VPL], int lane, int 
 // the group -- so the softmax, the K-sums and the weights carry the bits select_row<1> produces; arg-max ties go to the lowest
 // expert id in both.  Used by the one-pass router, where a wave owns 16 rows and 16 sequential wave-wide selections were a
 // 40 us tail on a 55 us stream (tools/router_bench.py).
+// Cross-lane steps as DPP row rotations (VALU speed) instead of __shfl_xor (ds_bpermute: an LDS round trip per step, ~25 dependent
+// ones per row pass -- a 21 us selection tail behind a 52 us stream at E = 64, tools/router_diag.py).  Inside a 16-lane row, after the
+// step with partner l ^ 8 (= rotation by 8) every value is replicated with period 8, so the partner l ^ 4 can be fetched as lane
+// l + 4 (rotation by 4), then l + 2, l + 1: the same pairs as the xor butterfly, level by level, hence the same bits (fp add and
+// max are commutative; the arg-max order is total).
+template <int N>
+__device__ __forceinline__ int dpp_ror_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false); }
+template <int N>
+__device__ __forceinline__ float dpp_ror(float v) { return __builtin_bit_cast(float, dpp_ror_i<N>(__builtin_bit_cast(int, v))); }
+
 __device__ __forceinline__ float g16_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 16));
+  v = fmaxf(v, dpp_ror<8>(v)); v = fmaxf(v, dpp_ror<4>(v)); v = fmaxf(v, dpp_ror<2>(v)); v = fmaxf(v, dpp_ror<1>(v));
   return v;
 }
 __device__ __forceinline__ float g16_sum64(const float (&x)[4]) {
   float v = (x[0] + x[2]) + (x[1] + x[3]);
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  v += dpp_ror<8>(v); v += dpp_ror<4>(v); v += dpp_ror<2>(v); v += dpp_ror<1>(v);
   return v;
 }
 __device__ __forceinline__ void g16_argmax(float& v, int& i) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {
-    float ov = __shfl_xor(v, o, 16);
-    int oi = __shfl_xor(i, o, 16);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+#define CSMOE_G16_STEP(N)                                                  \
+  {                                                                        \
+    const float ov = dpp_ror<N>(v);                                        \
+    const int oi = dpp_ror_i<N>(i);                                        \
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }                 \
   }
+  CSMOE_G16_STEP(8) CSMOE_G16_STEP(4) CSMOE_G16_STEP(2) CSMOE_G16_STEP(1)
+#undef CSMOE_G16_STEP
 }
 
 // s[j] = score of expert l16 + 16 j (-inf for experts >= E); `live` = this group's row exists (all lanes run the shuffles anyway)
