@@ -362,3 +362,15 @@ def test_quantised_weight_cache_follows_the_parameter_version():
     assert n4 == 4 and not torch.equal(o3, o0)
     assert torch.equal(o3, o4) and torch.equal(g3, g4) and all(torch.equal(a, b) for a, b in zip(p3, p4))
     Fn.fp8_weight_cache_clear()
+
+
+def test_both_orientation_quantiser_with_more_tiles_than_workgroups():
+    """A table of more than 16 384 tiles (the grid's cap per expert): workgroups walk several tiles, the next tile's loads in flight
+    while the current one is quantised.  Same bytes as the two single-orientation launches."""
+    x = torch.randn(32768, 8192, device=DEV) * torch.exp(torch.randn(32768, 1, device=DEV))
+    (q, s), (qt, st) = ops.quantize_mxfp8_both(x)
+    q1, s1 = ops.quantize_mxfp8(x)
+    assert torch.equal(q, q1) and torch.equal(s, s1)
+    del q, s, q1, s1
+    q2, s2 = ops.quantize_mxfp8(x, transpose=True)
+    assert torch.equal(qt, q2) and torch.equal(st, s2)
