@@ -69,6 +69,16 @@ def llava():
                 if g is not None and p.grad is not None:
                     worst = max(worst, rel_l2(p.grad, g.to(DEV)))
             line.append(f"worst-param-grad {worst:.2e}")
+            if bad > 0:
+                # rows routed unlike the reference's run (exact ties of its bf16 scores): the numbers above compare different routings;
+                # the comparison that means something is with the pinned oracle evaluated under the KERNEL's indices
+                with torch.no_grad():
+                    gidx = layer.topk_expert(layer.gate_logits(fx["x"].to(DEV)))[1].reshape(-1, layer.num_selected).cpu().long()
+                    aidx = layer.competition_policy(fx["x"].to(DEV))[1].reshape(gidx.shape[0], -1).cpu().long() \
+                        if hasattr(layer, "competition_policy") else None
+                oxg, og = TL.oracle_grads(fx, gidx, aidx)
+                w2 = max(rel_l2(p.grad.cpu(), og[k]) for k, p in layer.named_parameters() if og.get(k) is not None and p.grad is not None)
+                line.append(f"AGAINST THE ORACLE UNDER THE KERNEL'S INDICES: dx {rel_l2(x.grad.cpu(), oxg):.2e} worst-param-grad {w2:.2e}")
             print("  " + " | ".join(line))
 
 
@@ -83,6 +93,10 @@ def pretrain():
         layer, kw = TP.build(fx)
         bf16 = fx["meta"]["bf16"]
         x = fx["x"].to(DEV).requires_grad_(True)
+        spy = {}
+        if hasattr(layer, "ffn"):
+            ffn0 = layer.ffn
+            layer.ffn = lambda xx, sel, ww, *a, _f=ffn0, **k: (spy.setdefault("idx", sel.detach().cpu().long()), _f(xx, sel, ww, *a, **k))[1]
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
             out = layer(x, **kw)
             reg = layer.get_reg_loss()
@@ -98,6 +112,11 @@ def pretrain():
         line.append(f"dx {rel_l2(x.grad, fx['x_grad'].to(DEV)):.2e}")
         line.append("grads " + " ".join(f"{k}={rel_l2(p.grad, fx['grads'][k].to(DEV)):.2e}" for k, p in layer.named_parameters()
                                         if fx["grads"].get(k) is not None and p.grad is not None))
+        if bad > 0 and "idx" in spy and not fx["meta"].get("competition"):
+            oxg, og = TP.oracle_grads(fx, spy["idx"])
+            line.append("AGAINST THE ORACLE UNDER THE KERNEL'S INDICES: dx " + f"{rel_l2(x.grad.cpu(), oxg):.2e} grads " +
+                        " ".join(f"{k}={rel_l2(p.grad.cpu(), og[k]):.2e}" for k, p in layer.named_parameters()
+                                 if og.get(k) is not None and p.grad is not None))
         print("  " + " | ".join(line))
 
 
