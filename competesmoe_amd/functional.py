@@ -1082,10 +1082,11 @@ def _quantize_weight_both(t: torch.Tensor, cache: bool):
     if hit is not None and hit[0] == t._version:
         return hit[1]
     out = ops.quantize_mxfp8_both(t)
+    if hit is None:                                            # first entry under this key: it goes when its owner is freed
+        import weakref
+        owner = t._base if t._base is not None else t          # `keys_shared[0]` is a fresh view per call: the parameter owns the entry
+        weakref.finalize(owner, _FP8_WCACHE.pop, key, None)
     _FP8_WCACHE[key] = (t._version, out)
-    import weakref
-    owner = t._base if t._base is not None else t          # `keys_shared[0]` is a fresh view per call: the parameter owns the entry
-    weakref.finalize(owner, _FP8_WCACHE.pop, key, None)
     return out
 
 

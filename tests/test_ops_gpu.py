@@ -68,6 +68,32 @@ def test_dispatch_and_bwd(T, K, E, D, dtype):
     assert torch.allclose(dx2.float(), ref2.float(), rtol=tol, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,K,E,D", [(7, 2, 4, 8), (300, 3, 8, 64), (513, 4, 16, 200), (1024, 2, 64, 4096)])
+def test_dispatch_bwd_sequential_form_is_autograds_chain(T, K, E, D, dtype):
+    """csmoe_dispatch_rows_bwd with `idx` (+ `pre`, + `add`): x.dtype accumulation one expert at a time in DESCENDING expert order,
+    starting from `pre`, `add` last, a rounding after every add -- the order the reference's autograd adds the gradient streams of x
+    in for per-expert modules.  Against that chain written with tensor ops, bit for bit."""
+    idx = rand_idx(T, K, E, seed=D + K).to(DEV)
+    b = ops.bin_tokens(idx, E)
+    dxs = torch.randn(T * K, D, device=DEV).to(dtype)
+    pre = torch.randn(T, D, device=DEV).to(dtype)
+    add = torch.randn(T, D, device=DEV).to(dtype)
+    rows = dxs[b.slot_of.long()].view(T, K, D)                       # [t, k] = the row of expert idx[t, k]
+    order = torch.argsort(idx.long(), dim=-1, descending=True, stable=True)
+    for use_pre, use_add in ((True, True), (True, False), (False, True), (False, False)):
+        acc = pre.clone() if use_pre else torch.zeros(T, D, device=DEV, dtype=dtype)
+        for j in range(K):
+            acc = acc + rows[torch.arange(T, device=DEV), order[:, j]]          # a dtype add: rounded
+        if use_add:
+            acc = acc + add
+        got = ops.dispatch_rows_bwd(dxs, b, T, add=add if use_add else None, idx=idx, pre=pre if use_pre else None)
+        assert torch.equal(got, acc), (use_pre, use_add, float((got.float() - acc.float()).abs().max()))
+    # K <= 2 without a first addend: the chain IS the fp32 sum rounded once (what the fast kernel computes)
+    if K == 2:
+        assert torch.equal(ops.dispatch_rows_bwd(dxs, b, T, idx=idx), ops.dispatch_rows_bwd(dxs, b, T))
+
+
 # ------------------------------------------------------------------------------------------------ router
 def ref_select(scores, K, mode, round_bf16):
     s = scores.float()
