@@ -90,6 +90,10 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
                     help="fp8: BASELINE config 5 -- the pretrain stack's deepseekv2 layer (routed experts + --shared shared experts) with "
                          "GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 matrix pipe (fp32 master weights quantised directly, bf16 autocast)")
+    ap.add_argument("--weight-cache", action="store_true",
+                    help="--stack pretrain (bf16): keep the bf16 operand copies of the fp32 master weights while the parameters are unchanged "
+                         "(functional.weight_cache; the timed steps then model the micro-batches after the first of a gradient-accumulation "
+                         "step).  Off by default: every step converts the masters")
     ap.add_argument("--fp8-weight-cache", action="store_true",
                     help="--dtype fp8: keep the quantised expert weights while the parameters are unchanged (args.fp8_weight_cache; the timed "
                          "steps then model the micro-batches after the first of a gradient-accumulation step).  Off by default: every step quantises")
@@ -340,6 +344,9 @@ def main():
     if a.stack == "pretrain":
         assert world == 1 and not (a.force_ep or a.competition), "--stack pretrain: single-GPU smoe step (optionally --block) only"
         layer = make_pretrain_layer(a, dev)
+        if a.weight_cache:
+            from competesmoe_amd import functional as Fn
+            Fn.weight_cache(True)
     elif world > 1 or a.force_ep:
         assert a.experts % world == 0, "experts must divide over ranks"
         layer = make_layer(a, dev, dt, E_local=a.experts // world, seed=1 + rank)
@@ -496,7 +503,7 @@ def main():
             "metric": f"MoE-layer fwd+bwd tokens/sec at d_model={D}, {a.experts} experts top-{a.topk}", "value": round(total_tokens * a.steps / el, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": ((f"BASELINE config 5: pretrain-stack deepseekv2 layer, {a.experts} routed + {a.shared} shared experts, GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 matrix pipe (fp32 master weights quantised directly, bf16 weight gradients" + ("; quantised weights reused while the parameters are unchanged, as over the micro-batches of one optimizer step" if a.fp8_weight_cache else "; weights quantised every step") + "): " if a.dtype == "fp8" else "pretrain-stack layer (packed fp32 master weights, ReLU, no bias, bf16 autocast; weights cast to bf16 every step): ") if a.stack == "pretrain" else "") + ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
+            "config": {"workload": ((f"BASELINE config 5: pretrain-stack deepseekv2 layer, {a.experts} routed + {a.shared} shared experts, GEMM 1 / GEMM 2 / dH / dXs on the MXFP8 matrix pipe (fp32 master weights quantised directly, bf16 weight gradients" + ("; quantised weights reused while the parameters are unchanged, as over the micro-batches of one optimizer step" if a.fp8_weight_cache else "; weights quantised every step") + "): " if a.dtype == "fp8" else ("pretrain-stack layer (packed fp32 master weights, ReLU, no bias, bf16 autocast; bf16 operand copies reused while the parameters are unchanged, as over the micro-batches of one optimizer step): " if a.weight_cache else "pretrain-stack layer (packed fp32 master weights, ReLU, no bias, bf16 autocast; weights cast to bf16 every step): ")) if a.stack == "pretrain" else "") + ("block x + MoE(LayerNorm(x)) " + ("(fused LayerNorm+gate, residual in combine) around a " if a.block else "(unfused: torch LayerNorm + add) around a ") if (a.block or a.block_unfused) else "") + f"single sparse-MoE layer ({'competesmoe competition step' if a.competition else 'smoe routing'}), T={Bsz * Nseq} tokens/GPU as [{Bsz},{Nseq}], "
                                    f"d_model={D}, d_ff={a.d_ff}, {a.experts} experts top-{a.topk}, " + ("ReLU experts without bias, " if a.stack == "pretrain" else "Linear+bias/GELU experts, ") +
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
                        "graph_replay": bool(a.graph), "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
