@@ -202,52 +202,15 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
     WAIT_DMA(6);                                           // K-tile 0 landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    for (int s = 0; s < nk; ++s) {
-      const char* base = smem + (s & 1) * (4 * TILE_B);
-      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B;
-      bf16x8 fc[4][2], fr[4][2];
-      if (rlo && clo) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
-      }
-      if (rlo && chi) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
-      }
-      PHASE_SYNC_IN();                                     // every wave's reads of this slot are retired: it may be re-filled
-      __builtin_amdgcn_s_setprio(0);
-      ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      if (rlo && clo) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
-      if (rlo && chi) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 2; cb < 4; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
-      WAIT_DMA(6);                                         // K-tile s+1 landed (s+2 stays in flight)
-      PHASE_SYNC_OUT();
-    }
+#define THIN_FRAG_DECL bf16x8 fc[4][2], fr[4][2];
+#define THIN_READ_CL(cb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
+#define THIN_READ_CH(cb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
+#define THIN_READ_RL(rb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
+#define THIN_KSTEPS 2
+#define THIN_MFMA(ks, cb, rb) acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
+#define THIN_ISSUE(s) ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2)
+#define THIN_WAIT(s) WAIT_DMA(6)                           /* K-tile s+1 landed (s+2 stays in flight) */
+#include "gemm_loop_thin.inc"
   } else if constexpr (SCHED == BAL) {
     // WIDE with the work of the two phases cut by ROW image instead of by column image, so that the LDS reads and the DMA issue
     // are spread over both phases (WIDE reads 20 fragments in phase A and 4 in phase B):
@@ -267,81 +230,19 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
     __builtin_amdgcn_sched_barrier(0);
-    for (int s = 0; s < nk; ++s) {
-      const char* base = smem + (s & 1) * (4 * TILE_B);
-      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-      bf16x8 fc[4][2], fr[4][2];
-      // ---- phase A
-      if (clo && (rlo || rhi)) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
-      }
-      if (chi && (rlo || rhi)) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
-      }
-      if (rlo && clo) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
-      }
-      ISSUE_RH(s + 1);
-      WAIT_DMA(8);                                         // RH(s) landed
-      PHASE_SYNC_IN();
-      if (rlo && clo) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
-      if (rlo && chi) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 2; cb < 4; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
-      PHASE_SYNC_OUT();
-      // ---- phase B
-      if (rhi && clo) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
-      }
-      ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2);
-      WAIT_DMA(8);                                         // CL, CH, RL(s+1) landed
-      PHASE_SYNC_IN();
-      if (rhi && clo) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][4 + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][4 + rb], 0, 0, 0);
-      }
-      if (rhi && chi) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 2; cb < 4; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][4 + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][4 + rb], 0, 0, 0);
-      }
-      PHASE_SYNC_OUT();
-    }
+#define BAL_FRAG_DECL bf16x8 fc[4][2], fr[4][2];
+#define BAL_READ_CL(cb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
+#define BAL_READ_CH(cb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
+#define BAL_READ_RL(rb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
+#define BAL_READ_RH(rb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
+#define BAL_PHASE_A_EXTRA
+#define BAL_KSTEPS 2
+#define BAL_MFMA(ks, cb, rb, arb) acc[cb][arb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][arb], 0, 0, 0);
+#define BAL_ISSUE_A(s) ISSUE_RH(s + 1)
+#define BAL_ISSUE_B(s) ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2)
+#define BAL_WAIT_A(s) WAIT_DMA(8)                          /* RH(s) landed */
+#define BAL_WAIT_B(s) WAIT_DMA(8)                          /* CL, CH, RL(s+1) landed */
+#include "gemm_loop_bal.inc"
     if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
   } else if constexpr (SCHED == WIDE) {
     // TWO phases of 32 MFMA per K-tile (half the barriers of the 4-phase loop; all 8 row blocks stay in registers):
@@ -354,81 +255,17 @@ __global__ void __launch_bounds__(512, 2) gg8_kernel(FastArgs p) {
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
     __builtin_amdgcn_sched_barrier(0);
-    for (int s = 0; s < nk; ++s) {
-      const char* base = smem + (s & 1) * (4 * TILE_B);
-      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-      bf16x8 fc[2][2], fr[8][2];
-      // ---- phase A
-      if (actA) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
-      }
-      if (actA || actB) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
-      }
-      if (actAh || actBh) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
-      }
-      ISSUE_CL(s + 1); ISSUE_CH(s + 1);
-      WAIT_DMA(8);                                         // CH(s) landed
-      PHASE_SYNC_IN();
-      if (actA) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
-      if (actAh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 4; rb < 8; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
-      PHASE_SYNC_OUT();
-      // ---- phase B
-      if (actB) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
-      }
-      ISSUE_RL(s + 2); ISSUE_RH(s + 2);
-      WAIT_DMA(6);                                         // RL, RH, CL(s+1) landed
-      PHASE_SYNC_IN();
-      if (actB) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
-      }
-      if (actBh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 4; rb < 8; ++rb)
-              acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
-      }
-      PHASE_SYNC_OUT();
-    }
+#define WIDE_PRE_A(s)
+#define WIDE_PRE_B(s)
+#define WIDE_READ_CL(cb, ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_cl, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_cl, km_c[cb], ks);
+#define WIDE_READ_CH(cb, ks) fc[cb][ks] = (COLK == KC) ? frag_kc(i_ch, kc_lane, c_blk0 + cb, ks) : frag_km_raw(i_ch, km_c[cb], ks);
+#define WIDE_READ_RL(rb, ks) fr[rb][ks] = (ROWK == KC) ? frag_kc(i_rl, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rl, km_r[rb], ks);
+#define WIDE_READ_RH(rb, ks) fr[4 + rb][ks] = (ROWK == KC) ? frag_kc(i_rh, kc_lane, r_blk0 + rb, ks) : frag_km_raw(i_rh, km_r[rb], ks);
+#define WIDE_ISSUE_A(s) ISSUE_CL(s + 1); ISSUE_CH(s + 1)
+#define WIDE_ISSUE_B(s) ISSUE_RL(s + 2); ISSUE_RH(s + 2)
+#define WIDE_WAIT_A(s) WAIT_DMA(8)                         /* CH(s) landed */
+#define WIDE_WAIT_B(s) WAIT_DMA(6)                         /* RL, RH, CL(s+1) landed */
+#include "gemm_loop_wide.inc"
     if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
   }
 

@@ -187,84 +187,19 @@ __global__ void __launch_bounds__(512, 2) gg8c_kernel(CvtArgs p) {
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  for (int s = 0; s < nk; ++s) {
-    const char* base = smem + (s & 1) * (4 * TILE_B);
-    const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-    bf16x8 fc[2][2], fr[8][2];
-    // ---- phase A: CH(s) from the registers into LDS; fragments of CL, RL, RH(s); loads of CL(s+1)
-    WAIT_W(4);                                             // CH(s) quads are in (the 4 row pieces issued after them stay in flight)
-    STORE_IMG(2, 1, s);
-    if (actA) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_cl, km_c[cb], ks);
-    }
-    if (actA || actB) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_kc(i_rl, kc_lane, r_blk0 + rb, ks);
-    }
-    if (actAh || actBh) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = frag_kc(i_rh, kc_lane, r_blk0 + rb, ks);
-    }
-    LOAD_IMG(0, s + 1);
-    PHASE_SYNC_IN();
-    if (actA) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-    }
-    if (actAh) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int rb = 4; rb < 8; ++rb)
-            acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-    }
-    PHASE_SYNC_OUT();
-    // ---- phase B: CL(s+1) from the registers into LDS; fragments of CH(s); loads of CH(s+1); row pieces of K-tile s+2
-    WAIT_W(0);                                             // CL(s+1) quads are in; so are the row pieces of K-tile s+1 (a phase old)
-    STORE_IMG(1, 0, s + 1);
-    if (actB) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
-    }
-    LOAD_IMG(1, s + 1);
-    ISSUE_RL(s + 2); ISSUE_RH(s + 2);
-    PHASE_SYNC_IN();
-    if (actB) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
-            acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
-    }
-    if (actBh) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int rb = 4; rb < 8; ++rb)
-            acc[2 + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[2 + cb][rb], 0, 0, 0);
-    }
-    PHASE_SYNC_OUT();
-  }
+  // phase A: CH(s) from the registers into LDS; fragments of CL, RL, RH(s); loads of CL(s+1)
+  // phase B: CL(s+1) from the registers into LDS; fragments of CH(s); loads of CH(s+1); row pieces of K-tile s+2
+#define WIDE_PRE_A(s) WAIT_W(4); /* CH(s) quads are in (the 4 row pieces issued after them stay in flight) */ STORE_IMG(2, 1, s);
+#define WIDE_PRE_B(s) WAIT_W(0); /* CL(s+1) quads are in; so are the row pieces of K-tile s+1 (a phase old) */ STORE_IMG(1, 0, s + 1);
+#define WIDE_READ_CL(cb, ks) fc[cb][ks] = frag_km_raw(i_cl, km_c[cb], ks);
+#define WIDE_READ_CH(cb, ks) fc[cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
+#define WIDE_READ_RL(rb, ks) fr[rb][ks] = frag_kc(i_rl, kc_lane, r_blk0 + rb, ks);
+#define WIDE_READ_RH(rb, ks) fr[4 + rb][ks] = frag_kc(i_rh, kc_lane, r_blk0 + rb, ks);
+#define WIDE_ISSUE_A(s) LOAD_IMG(0, s + 1)
+#define WIDE_ISSUE_B(s) LOAD_IMG(1, s + 1); ISSUE_RL(s + 2); ISSUE_RH(s + 2)
+#define WIDE_WAIT_A(s)
+#define WIDE_WAIT_B(s)
+#include "gemm_loop_wide.inc"
   if (wm == 0) __builtin_amdgcn_s_barrier();
 
   // the loads / zero-fill DMAs of the K-tiles past the end may still be in flight: drain before the staging tile reuses LDS

@@ -18,8 +18,8 @@
 // Tried and dropped (same box A/B, tools/gemm_bench.py): storing the accumulators straight from registers (32-byte row
 // segments per store: -6 %); a software-pipelined loop with single-buffered just-in-time fragments and ONE barrier per K-tile
 // (2.64k cycles per K-tile with cache-resident operands, but 3.2k with real ones: its prefetch lead is one K-tile where the
-// staggered loop has 1.5); the split DMA schedule below is +1..2 % here and -3..6 % in the long-K row-space launches, which
-// keep all DMA issue in the read sections.
+// staggered loop has 1.5); a column-cut schedule with the DMA pieces of two images moved between the MFMAs (5.62 ms per headline
+// launch against 5.55 for the row-cut loop; removed in round 3, commit 5bc2f9d has it).
 // Both operands are K-major ([rows, features]): KM images read with ds_read_b64_tr_b16.
 #include "gemm_tiles.h"
 #include <algorithm>
@@ -118,9 +118,8 @@ __device__ __forceinline__ DmaW dma_of(const FastArgs& p, const TileW& t_in, uns
   return d;
 }
 
-// SCHED 0: the split two-phase schedule described below (phases cut by COLUMN image).  SCHED 1 ("BAL"): phases cut by ROW image,
+// The K-loop is the row-cut two-phase loop shared with the row-space kernels (gemm_loop_bal.inc): phases cut by ROW image,
 // see gemm_bf16_v2.hip -- A reads CL, CH, RL(s) and issues RH(s+1), B reads RH(s) and issues CL, CH, RL(s+2), vmcnt(8) in both.
-template <int SCHED>
 __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -225,27 +224,7 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
     // ragged tiles: a wave whose strips lie outside the tile skips those reads and MFMAs (it still issues its DMA share)
     const int rows_here = min(BM2, p.NR - cur.tr0) - wm * 64;
     const int cols_here = min(BN2, p.NC - cur.tc0) - wn * 32;
-    const bool actA = rows_here > 0 && cols_here > 0, actAh = rows_here > 128 && cols_here > 0;
-    const bool actB = rows_here > 0 && cols_here > 128, actBh = rows_here > 128 && cols_here > 128;
-
-    // Split DMA schedule: the 8 pieces a wave issues per K-tile are spread so that no segment carries both the 40 fragment
-    // reads of phase A and DMA issue (an LDS-DMA piece costs its wave 100-185 cycles next to ds_reads, ~60 between MFMAs):
-    //     LA(s): read CL, RL, RH(s)               vmcnt(6): CH(s) landed
-    //     MA(s): 32 MFMA + CH(s+1) (2 pieces, after the 8th and 24th MFMA)
-    //     LB(s): read CH(s)   issue RL, RH(s+2)   vmcnt(6): RL, RH, CL(s+1) landed
-    //     MB(s): 32 MFMA + CL(s+2) (2 pieces)
-    // Issue order per wave: ... RL,RH(s+2) | CL(s+2) | CH(s+2) | RL,RH(s+3) ...; every slot is refilled only after the
-    // barrier that follows the staggered half's read of it.
-#define PIECE_CL(tile, j) dma_piece<KM, 2>(dcur.rs_c, SLOT(1, tile), dcur.vb_cl[j], 0, j, (tile) * BK2, cur.red_len, ldc_b, wave)
-#define PIECE_CH(tile, j) dma_piece<KM, 2>(dcur.rs_c, SLOT(2, tile), dcur.vb_ch[j], 0, j, (tile) * BK2, cur.red_len, ldc_b, wave)
-#define MFMA_HALF(COND, CB0, RB0, KS)                                                                              \
-    if (COND) {                                                                                                      \
-      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)                                                               \
-        _Pragma("unroll") for (int rb = (RB0); rb < (RB0) + 4; ++rb)                                                 \
-          acc[(CB0) + cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][KS], fr[rb][KS], acc[(CB0) + cb][rb], 0, 0, 0); \
-    }
-#define PINNED(X) __builtin_amdgcn_sched_barrier(0); X; __builtin_amdgcn_sched_barrier(0)
-    if constexpr (SCHED == 1) {
+    {
     const bool rlo = rows_here > 0, rhi = rows_here > 128, clo = cols_here > 0, chi = cols_here > 128;
     ISSUE_CL(dcur, cur, 1); ISSUE_CH(dcur, cur, 1); ISSUE_RL(dcur, cur, 1);
     if (first) {
@@ -255,136 +234,19 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
     if (wm == 1) __builtin_amdgcn_s_barrier();               // row half 1 starts half a phase late
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
-    for (int s = 0; s < nk; ++s) {
-      const char* base = smem + (s & 1) * (4 * TILE_B);
-      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-      bf16x8 fc[4][2], fr[4][2];
-      if (clo && (rlo || rhi)) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_cl, km_c[cb], ks);
-      }
-      if (chi && (rlo || rhi)) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
-      }
-      if (rlo && clo) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_km_raw(i_rl, km_r[rb], ks);
-      }
-      ISSUE_RH(dcur, cur, s + 1);
-      if (s > 0 || first) WAIT_DMA(8);                     // RH(s) landed
-      PHASE_SYNC_IN();
-      if (rlo && clo) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
-      if (rlo && chi) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 2; cb < 4; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][rb], 0, 0, 0);
-      }
-      PHASE_SYNC_OUT();
-      if (rhi && clo) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_km_raw(i_rh, km_r[rb], ks);
-      }
-      ISSUE_CL(dcur, cur, s + 2); ISSUE_CH(dcur, cur, s + 2); ISSUE_RL(dcur, cur, s + 2);
-      WAIT_DMA(8);                                         // CL, CH, RL(s+1) landed
-      PHASE_SYNC_IN();
-      if (rhi && clo) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][4 + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][4 + rb], 0, 0, 0);
-      }
-      if (rhi && chi) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 2; cb < 4; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-              acc[cb][4 + rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][4 + rb], 0, 0, 0);
-      }
-      PHASE_SYNC_OUT();
-    }
-    } else {
-    ISSUE_RL(dcur, cur, 1); ISSUE_RH(dcur, cur, 1); ISSUE_CL(dcur, cur, 1);
-    if (first) {
-      WAIT_DMA(8);                                           // RL, RH, CL(0) landed (CH(0) is checked in LA(0))
-      __builtin_amdgcn_s_barrier();
-    }                                                        // later tiles: K-tile 0 confirmed in the previous epilogue
-    if (wm == 1) __builtin_amdgcn_s_barrier();               // row half 1 starts half a phase late
-    __builtin_amdgcn_sched_barrier(0);
-    STAMP(1);
-    for (int s = 0; s < nk; ++s) {
-      const char* base = smem + (s & 1) * (4 * TILE_B);
-      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-      bf16x8 fc[2][2], fr[8][2];
-      if (actA) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_cl, km_c[cb], ks);
-      }
-      if (actA || actB) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_km_raw(i_rl, km_r[rb], ks);
-      }
-      if (actAh || actBh) {
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fr[4 + rb][ks] = frag_km_raw(i_rh, km_r[rb], ks);
-      }
-      if (s > 0 || first) WAIT_DMA(6);                     // CH(s) landed
-      PHASE_SYNC_IN();
-      MFMA_HALF(actA, 0, 0, 0)
-      PINNED(PIECE_CH(s + 1, 0));
-      MFMA_HALF(actA, 0, 0, 1)
-      MFMA_HALF(actAh, 0, 4, 0)
-      PINNED(PIECE_CH(s + 1, 1));
-      MFMA_HALF(actAh, 0, 4, 1)
-      PHASE_SYNC_OUT();
-      if (actB) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
-      }
-      ISSUE_RL(dcur, cur, s + 2); ISSUE_RH(dcur, cur, s + 2);
-      WAIT_DMA(6);                                         // RL, RH, CL(s+1) landed
-      PHASE_SYNC_IN();
-      MFMA_HALF(actB, 2, 0, 0)
-      PINNED(PIECE_CL(s + 2, 0));
-      MFMA_HALF(actB, 2, 0, 1)
-      MFMA_HALF(actBh, 2, 4, 0)
-      PINNED(PIECE_CL(s + 2, 1));
-      MFMA_HALF(actBh, 2, 4, 1)
-      PHASE_SYNC_OUT();
-    }
+#define BAL_FRAG_DECL bf16x8 fc[4][2], fr[4][2];
+#define BAL_READ_CL(cb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fc[cb][ks] = frag_km_raw(i_cl, km_c[cb], ks);
+#define BAL_READ_CH(cb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fc[2 + cb][ks] = frag_km_raw(i_ch, km_c[cb], ks);
+#define BAL_READ_RL(rb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_km_raw(i_rl, km_r[rb], ks);
+#define BAL_READ_RH(rb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fr[rb][ks] = frag_km_raw(i_rh, km_r[rb], ks);
+#define BAL_PHASE_A_EXTRA
+#define BAL_KSTEPS 2
+#define BAL_MFMA(ks, cb, rb, arb) acc[cb][arb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[cb][ks], fr[rb][ks], acc[cb][arb], 0, 0, 0);
+#define BAL_ISSUE_A(s) ISSUE_RH(dcur, cur, s + 1)
+#define BAL_ISSUE_B(s) ISSUE_CL(dcur, cur, s + 2); ISSUE_CH(dcur, cur, s + 2); ISSUE_RL(dcur, cur, s + 2)
+#define BAL_WAIT_A(s) if (s > 0 || first) WAIT_DMA(8)     /* RH(s) landed (later tiles: K-tile 0 confirmed in the previous epilogue) */
+#define BAL_WAIT_B(s) WAIT_DMA(8)                          /* CL, CH, RL(s+1) landed */
+#include "gemm_loop_bal.inc"
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();             // row half 0 waits for the staggered half to finish
     STAMP(2);
@@ -567,25 +429,14 @@ int persistent_grid(int64_t tiles_upper) {
   return (int)std::min<int64_t>(tiles_upper, ncu);
 }
 
-template <int SCHED>
 int set_lds2() {
   static bool done = false;
   if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gg8w_kernel<SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gg8w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES);
     if (e != hipSuccess) { csmoe_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return CSMOE_ERR_LAUNCH; }
     done = true;
   }
   return CSMOE_OK;
-}
-
-int wgrad_sched() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CSMOE_WGRAD_SCHED");      // A/B: 0 = column-cut phases with the split DMA placement, 1 = BAL
-    v = e ? atoi(e) : 1;                              // same box: 5.62 (0) / 5.55 (1) ms per headline launch; BAL with RH / RL pieces
-                                                      // moved between the MFMAs like schedule 0 does: 5.58, removed
-  }
-  return v;
 }
 
 }  // namespace
@@ -605,16 +456,14 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
   if (grid <= 0) return CSMOE_OK;
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_wgrad: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;
-  const int ws = wgrad_sched();
-  if ((rc = ws == 1 ? set_lds2<1>() : set_lds2<0>())) return rc;
+  if ((rc = set_lds2())) return rc;
 #ifdef CSMOE_STAMPS
   static unsigned long long* dbg = nullptr;
   if (!dbg) (void)hipMalloc(&dbg, 24 * 16 * 8);
   (void)hipMemsetAsync(dbg, 0, 24 * 16 * 8, st);
   p.aux = dbg;
 #endif
-  if (ws == 1) hipLaunchKernelGGL(gg8w_kernel<1>, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
-  else         hipLaunchKernelGGL(gg8w_kernel<0>, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
+  hipLaunchKernelGGL(gg8w_kernel, dim3((unsigned)persistent_grid(grid)), dim3(512), LDS2_BYTES, st, p);
 #ifdef CSMOE_STAMPS
   {
     static unsigned long long h[24 * 16];

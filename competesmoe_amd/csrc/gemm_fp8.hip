@@ -146,51 +146,15 @@ __global__ void __launch_bounds__(512, 2) gg8f_kernel(Fp8Args p) {
     WAIT_DMA(7);                                           // K-tile 0 landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    for (int s = 0; s < nk; ++s) {
-      const char* base = smem + (s & 1) * (4 * TILE_B);
-      const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B;
-      const char* sc = SCSLOT(s);
-      i32x8 fc[4], fr[4];
-      int sc_c[4], sc_r[4];
-      if (rlo && clo) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          fc[cb] = FRAG(i_cl, c_blk0 + cb);
-          sc_c[cb] = *(const uint8_t*)(sc + 1024 + ((c_blk0 + cb) * 16 + i16) * 4 + g);
-        }
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          fr[rb] = FRAG(i_rl, r_blk0 + rb);
-          sc_r[rb] = *(const uint8_t*)(sc + ((r_blk0 + rb) * 16 + i16) * 4 + g);
-        }
-      }
-      if (rlo && chi) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          fc[2 + cb] = FRAG(i_ch, c_blk0 + cb);
-          sc_c[2 + cb] = *(const uint8_t*)(sc + 1024 + (128 + (c_blk0 + cb) * 16 + i16) * 4 + g);
-        }
-      }
-      PHASE_SYNC_IN();                                     // every wave's reads of this slot are retired: it may be re-filled
-      __builtin_amdgcn_s_setprio(0);
-      ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2); ISSUE_SC(s + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      if (rlo && clo) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb) MFMA8(acc[cb][rb], fc[cb], fr[rb], sc_c[cb], sc_r[rb]);
-      }
-      if (rlo && chi) {
-#pragma unroll
-        for (int cb = 2; cb < 4; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 4; ++rb) MFMA8(acc[cb][rb], fc[cb], fr[rb], sc_c[cb], sc_r[rb]);
-      }
-      WAIT_DMA(7);                                         // K-tile s+1 landed (s+2 stays in flight)
-      PHASE_SYNC_OUT();
-    }
+#define THIN_FRAG_DECL const char* sc = SCSLOT(s); i32x8 fc[4], fr[4]; int sc_c[4], sc_r[4];
+#define THIN_READ_CL(cb) fc[cb] = FRAG(i_cl, c_blk0 + cb); sc_c[cb] = *(const uint8_t*)(sc + 1024 + ((c_blk0 + cb) * 16 + i16) * 4 + g);
+#define THIN_READ_CH(cb) fc[2 + cb] = FRAG(i_ch, c_blk0 + cb); sc_c[2 + cb] = *(const uint8_t*)(sc + 1024 + (128 + (c_blk0 + cb) * 16 + i16) * 4 + g);
+#define THIN_READ_RL(rb) fr[rb] = FRAG(i_rl, r_blk0 + rb); sc_r[rb] = *(const uint8_t*)(sc + ((r_blk0 + rb) * 16 + i16) * 4 + g);
+#define THIN_KSTEPS 1
+#define THIN_MFMA(ks, cb, rb) MFMA8(acc[cb][rb], fc[cb], fr[rb], sc_c[cb], sc_r[rb]);
+#define THIN_ISSUE(s) ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2); ISSUE_SC(s + 2)
+#define THIN_WAIT(s) WAIT_DMA(7)                           /* K-tile s+1 landed (s+2 stays in flight) */
+#include "gemm_loop_thin.inc"
   } else {
   // issue order ... [CL,CH,RL,SC](s+1) | RH(s+1) | [CL,CH,RL,SC](s+2) | RH(s+2) ...: 7 + 2 pieces per K-tile and wave, so the
   // counted waits of the bf16 loop (8) become 9
@@ -199,76 +163,23 @@ __global__ void __launch_bounds__(512, 2) gg8f_kernel(Fp8Args p) {
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();             // row half 1 starts half a phase late
   __builtin_amdgcn_sched_barrier(0);
-  for (int s = 0; s < nk; ++s) {
-    const char* base = smem + (s & 1) * (4 * TILE_B);
-    const char* i_rl = base, *i_cl = base + TILE_B, *i_ch = base + 2 * TILE_B, *i_rh = base + 3 * TILE_B;
-    const char* sc = SCSLOT(s);
-    i32x8 fc[4], fr[4];
-    int sc_c[4], sc_r[8];
-    // ---- phase A: read CL, CH, RL(s) and ALL scales of K-tile s, issue RH(s+1), MFMA C_all x R_lo
-    if (clo && (rlo || rhi)) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        fc[cb] = FRAG(i_cl, c_blk0 + cb);
-        sc_c[cb] = *(const uint8_t*)(sc + 1024 + ((c_blk0 + cb) * 16 + i16) * 4 + g);
-      }
-    }
-    if (chi && (rlo || rhi)) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        fc[2 + cb] = FRAG(i_ch, c_blk0 + cb);
-        sc_c[2 + cb] = *(const uint8_t*)(sc + 1024 + (128 + (c_blk0 + cb) * 16 + i16) * 4 + g);
-      }
-    }
-    if (rlo && clo) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        fr[rb] = FRAG(i_rl, r_blk0 + rb);
-        sc_r[rb] = *(const uint8_t*)(sc + ((r_blk0 + rb) * 16 + i16) * 4 + g);
-      }
-    }
-    if (rhi && clo) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) sc_r[4 + rb] = *(const uint8_t*)(sc + (128 + (r_blk0 + rb) * 16 + i16) * 4 + g);
-    }
-    ISSUE_RH(s + 1);
-    WAIT_DMA(9);                                         // RH(s) landed
-    PHASE_SYNC_IN();
-    if (rlo && clo) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) MFMA8(acc[cb][rb], fc[cb], fr[rb], sc_c[cb], sc_r[rb]);
-    }
-    if (rlo && chi) {
-#pragma unroll
-      for (int cb = 2; cb < 4; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) MFMA8(acc[cb][rb], fc[cb], fr[rb], sc_c[cb], sc_r[rb]);
-    }
-    PHASE_SYNC_OUT();
-    // ---- phase B: read RH(s), issue CL, CH, RL, SC(s+2), MFMA C_all x R_hi
-    if (rhi && clo) {
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) fr[rb] = FRAG(i_rh, r_blk0 + rb);
-    }
-    ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2); ISSUE_SC(s + 2);
-    WAIT_DMA(9);                                         // CL, CH, RL, SC(s+1) landed
-    PHASE_SYNC_IN();
-    if (rhi && clo) {
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) MFMA8(acc[cb][4 + rb], fc[cb], fr[rb], sc_c[cb], sc_r[4 + rb]);
-    }
-    if (rhi && chi) {
-#pragma unroll
-      for (int cb = 2; cb < 4; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) MFMA8(acc[cb][4 + rb], fc[cb], fr[rb], sc_c[cb], sc_r[4 + rb]);
-    }
-    PHASE_SYNC_OUT();
+  // phase A also reads ALL scales of K-tile s (the RH rows' too); a K = 128 MFMA per (column block, row block) and K-tile
+#define BAL_FRAG_DECL const char* sc = SCSLOT(s); i32x8 fc[4], fr[4]; int sc_c[4], sc_r[8];
+#define BAL_READ_CL(cb) fc[cb] = FRAG(i_cl, c_blk0 + cb); sc_c[cb] = *(const uint8_t*)(sc + 1024 + ((c_blk0 + cb) * 16 + i16) * 4 + g);
+#define BAL_READ_CH(cb) fc[2 + cb] = FRAG(i_ch, c_blk0 + cb); sc_c[2 + cb] = *(const uint8_t*)(sc + 1024 + (128 + (c_blk0 + cb) * 16 + i16) * 4 + g);
+#define BAL_READ_RL(rb) fr[rb] = FRAG(i_rl, r_blk0 + rb); sc_r[rb] = *(const uint8_t*)(sc + ((r_blk0 + rb) * 16 + i16) * 4 + g);
+#define BAL_READ_RH(rb) fr[rb] = FRAG(i_rh, r_blk0 + rb);
+#define BAL_PHASE_A_EXTRA                                                                                                      \
+  if (rhi && clo) {                                                                                                            \
+    _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) sc_r[4 + rb] = *(const uint8_t*)(sc + (128 + (r_blk0 + rb) * 16 + i16) * 4 + g); \
   }
+#define BAL_KSTEPS 1
+#define BAL_MFMA(ks, cb, rb, arb) MFMA8(acc[cb][arb], fc[cb], fr[rb], sc_c[cb], sc_r[arb]);
+#define BAL_ISSUE_A(s) ISSUE_RH(s + 1)
+#define BAL_ISSUE_B(s) ISSUE_CL(s + 2); ISSUE_CH(s + 2); ISSUE_RL(s + 2); ISSUE_SC(s + 2)
+#define BAL_WAIT_A(s) WAIT_DMA(9)                          /* RH(s) landed */
+#define BAL_WAIT_B(s) WAIT_DMA(9)                          /* CL, CH, RL, SC(s+1) landed */
+#include "gemm_loop_bal.inc"
   if (wm == 0) __builtin_amdgcn_s_barrier();
   }
 
