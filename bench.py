@@ -109,6 +109,8 @@ def parse():
     ap.add_argument("--ep-chunks", type=int, default=0, help="expert-parallel runs: groups of local experts whose all-to-all overlaps the grouped GEMMs (competesmoe_amd.ep); 0 = pick the fastest of 1 / 2 / 4 in a short untimed trial before the warmup (1 with a single rank)")
     ap.add_argument("--ep-trial", action="store_true", help="run the overlap-depth trial even with a single rank (exercises the N>1 control flow on one GPU)")
     ap.add_argument("--stub", action="store_true", help="launcher test: CPU stand-in step over gloo, no GPU (tests/test_bench_launcher.py)")
+    ap.add_argument("--ep-direct", action="store_true", help="expert-parallel runs: one message per (peer, local expert) delivered expert-major "
+                    "(no regroup passes; EPSMoeLayer(direct=True)).  Off by default, see DESIGN section 5")
     ap.add_argument("--force-ep", action="store_true", help="use the expert-parallel layer even with one rank (smoke-tests the N>1 code path)")
     return ap.parse_args()
 
@@ -407,6 +409,7 @@ def main():
 
     ep_tune = None
     if world > 1 or a.force_ep:
+        layer.direct = bool(a.ep_direct)
         if a.ep_chunks > 0 or (world == 1 and not a.ep_trial):
             layer.chunks = max(1, a.ep_chunks)
         else:   # untimed trial: overlap depth that is fastest on THIS node (max over ranks, so every rank picks the same)
@@ -508,7 +511,7 @@ def main():
                                    f"fwd+bwd incl. expert weight grads" + (", skewed gate" if a.skew else ""),
                        "graph_replay": bool(a.graph), "tokens_per_gpu": Bsz * Nseq, "d_model": D, "d_ff": a.d_ff, "experts": a.experts, "top_k": a.topk,
                        "parallelism": "single GPU" if world == 1 else f"ep{world} (experts sharded, RCCL all-to-all)",
-                       **({"ep_chunks": layer.chunks, "ep_chunks_trial_ms": ep_tune, "comm_world_size": dist.get_world_size(),
+                       **({"ep_chunks": layer.chunks, "ep_direct": bool(a.ep_direct), "ep_chunks_trial_ms": ep_tune, "comm_world_size": dist.get_world_size(),
                            "comm_backend": "nccl (RCCL)"} if (world > 1 or a.force_ep) else {})},
             "roofline": roof, "kernels": detail,
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),

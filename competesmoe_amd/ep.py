@@ -154,6 +154,79 @@ def local_expert_ids(plan: EPPlan, e0: int = 0, e1: Optional[int] = None) -> tor
     return torch.repeat_interleave(pattern, cnt.flatten().long(), output_size=R)
 
 
+# ---- direct exchange: one message per (peer, local expert), delivered where the grouped GEMM wants it (no regroup passes) ----------
+def _direct_default() -> bool:
+    return os.environ.get("CSMOE_EP_DIRECT", "0") == "1"
+
+
+def direct_views(buf: torch.Tensor, plan: EPPlan, e0: int, e1: int, local: bool):
+    """Row views of `buf` for the experts [e0, e1) of every peer, as [(peer, view)] in the canonical message order (peer-major,
+    expert ascending -- the order both ends of a pair issue their sends / receives in).
+    local = False: `buf` is this rank's BINNED row space (rows sorted by global expert id): the rows of peer p's local expert e.
+    local = True:  `buf` holds ONLY the rows received for my experts [e0, e1), expert-major (expert e's rows contiguous, ordered
+    by source rank inside): the rows that came from peer p for my expert e."""
+    P, El = plan.P, plan.E_local
+    out = []
+    if not local:
+        goff = torch.zeros(P * El + 1, dtype=torch.int64)
+        goff[1:] = plan.send_host.flatten().cumsum(0)
+        for pr in range(P):
+            for e in range(e0, e1):
+                a = int(goff[pr * El + e])
+                out.append((pr, buf[a:a + int(plan.send_host[pr, e])]))
+        return out
+    rh = plan.recv_host[:, e0:e1]                                  # [P, e1 - e0]
+    ebase = torch.zeros(e1 - e0 + 1, dtype=torch.int64)
+    ebase[1:] = rh.sum(0).cumsum(0)
+    within = torch.zeros_like(rh)
+    within[1:] = rh.cumsum(0)[:-1]                                # rows of expert e that came from lower ranks
+    for pr in range(P):
+        for j in range(e1 - e0):
+            a = int(ebase[j] + within[pr, j])
+            out.append((pr, buf[a:a + int(rh[pr, j])]))
+    return out
+
+
+def local_bins(plan: EPPlan, e0: int, e1: int) -> "ops.Bins":
+    """The binned row space of an expert-major receive buffer: offsets from the received counts, on the device (no host read)."""
+    cnt = plan.recv_counts[:, e0:e1].sum(0).int()
+    off = torch.zeros(e1 - e0 + 1, dtype=torch.int32, device=cnt.device)
+    off[1:] = cnt.cumsum(0)
+    n = int(plan.recv_host[:, e0:e1].sum())
+    return ops.Bins(cnt, off, None, None, n, e1 - e0, 1)
+
+
+class _Works:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
+
+
+def exchange_direct(dst, src, group=None):
+    """dst / src: [(peer, view)] lists of equal length in the canonical order: view i of `src` goes to its peer, view i of `dst` is
+    filled by its peer (matching is by order per pair, as RCCL matches grouped send / recv).  Empty views are skipped on both ends
+    (the counts agree: my send count to p for e IS p's receive count from me for e); the self pair is a device copy.  One grouped
+    launch (`batch_isend_irecv`) on the process group's stream; returns a handle whose wait() orders the current stream after it."""
+    me = dist.get_rank(group)
+    p2p = []
+    for (ps, vs), (pd, vd) in zip(src, dst):
+        assert ps == pd
+        if ps == me:
+            if vd.shape[0]:
+                vd.copy_(vs)
+            continue
+        peer = ps if group is None else dist.get_global_rank(group, ps)
+        if vs.shape[0]:
+            p2p.append(dist.P2POp(dist.isend, vs, peer, group))
+        if vd.shape[0]:
+            p2p.append(dist.P2POp(dist.irecv, vd, peer, group))
+    return _Works(dist.batch_isend_irecv(p2p) if p2p else [])
+
+
 # ------------------------------------------------------------------------------------------------ the EP FFN
 class _Unsort:
     """Adapter so ops.dispatch_rows can apply the inverse of a K=1 binning (out[m] = sorted[slot_of[m]])."""
@@ -165,24 +238,37 @@ class EPFFN(torch.autograd.Function):
     """dispatch -> all-to-all -> local grouped FFN -> all-to-all -> combine, and the mirrored backward."""
 
     @staticmethod
-    def forward(ctx, x2, w, idx, tab: ExpertTable, E_global: int, group, combine_mode: int, want_slots: bool, *params):
+    def forward(ctx, x2, w, idx, tab: ExpertTable, E_global: int, group, combine_mode: int, want_slots: bool, direct: bool, *params):
         """Returns (out [T, Dout], y_tk): the combined output and, with `want_slots`, the expert outputs per (token, k) slot in flat
         order [T*K, Dout] -- what `torch.gather(expert_outputs, idx)` gives the single-GPU competition step for its diversity
-        loss (an empty tensor otherwise); gradients of both are accepted."""
+        loss (an empty tensor otherwise); gradients of both are accepted.
+        `direct`: one message per (peer, local expert) straight into an expert-major buffer (exchange_direct) instead of one per peer
+        followed by a regroup pass (and its inverse before the return trip); same rows through the same kernels."""
         x2 = x2.contiguous()
         T = x2.shape[0]
         bins = ops.bin_tokens(idx, E_global)
         xs = ops.dispatch_tokens(x2, bins)
-        plan = make_plan(bins.counts, group)
-        recv = a2a_rows(xs, plan.send_splits, plan.recv_splits, group)
-        lb = ops.bin_tokens(local_expert_ids(plan).view(-1, 1), tab.E)
-        rs = ops.dispatch_rows(recv, lb)
+        plan = make_plan(bins.counts, group, per_expert=direct)
+        El = plan.E_local
+        if direct:
+            rs = torch.empty(plan.R, xs.shape[1], dtype=xs.dtype, device=xs.device)
+            exchange_direct(direct_views(rs, plan, 0, El, True), direct_views(xs, plan, 0, El, False), group).wait()
+            lb = local_bins(plan, 0, El)
+        else:
+            recv = a2a_rows(xs, plan.send_splits, plan.recv_splits, group)
+            lb = ops.bin_tokens(local_expert_ids(plan).view(-1, 1), tab.E)
+            rs = ops.dispatch_rows(recv, lb)
         hpre, hact = ops.grouped_gemm(rs, tab.w1_ptrs, tab.layout, tab.D, tab.F, lb.offsets, tab.E, bias_ptrs=tab.b1_ptrs,
                                       epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True, want_c=tab.act != L.ACT_RELU)
         ys = ops.grouped_gemm(hact, tab.w2_ptrs, tab.layout, tab.F, tab.Dout, lb.offsets, tab.E, bias_ptrs=tab.b2_ptrs,
                               epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
-        y = a2a_rows(ops.dispatch_rows(ys, _Unsort(lb)), plan.recv_splits, plan.send_splits, group)
+        if direct:
+            y = torch.empty(bins.n, ys.shape[1], dtype=ys.dtype, device=ys.device)
+            exchange_direct(direct_views(y, plan, 0, El, False), direct_views(ys, plan, 0, El, True), group).wait()
+        else:
+            y = a2a_rows(ops.dispatch_rows(ys, _Unsort(lb)), plan.recv_splits, plan.send_splits, group)
         out = ops.combine(y, bins, idx, w, combine_mode, T)
+        ctx.direct = direct
         ctx.saved = (bins, lb, plan, rs, hpre, hact, y)
         ctx.tab, ctx.w, ctx.group, ctx.n_params = tab, w, group, len(params)
         ctx.want_slots = want_slots
@@ -204,11 +290,16 @@ class EPFFN(torch.autograd.Function):
         dy, dw = ops.combine_bwd(dout.contiguous(), y, bins, ctx.w, want_dw=ctx.needs_input_grad[1], round_products=ctx.round_dw)
         if dy_tk is not None and ctx.want_slots:               # gradient of the per-slot outputs (diversity loss), binned order
             dy = dy + ops.dispatch_rows(dy_tk.contiguous(), ops.Bins(None, None, bins.perm, None, bins.n, bins.E, 1))
-        dys = ops.dispatch_rows(a2a_rows(dy, plan.send_splits, plan.recv_splits, group), lb)
+        El = plan.E_local
+        if ctx.direct:
+            dys = torch.empty(plan.R, dy.shape[1], dtype=dy.dtype, device=dev)
+            exchange_direct(direct_views(dys, plan, 0, El, True), direct_views(dy, plan, 0, El, False), group).wait()
+        else:
+            dys = ops.dispatch_rows(a2a_rows(dy, plan.send_splits, plan.recv_splits, group), lb)
         dh = ops.grouped_gemm(dys, tab.w2_ptrs, L.B_KN, tab.F, tab.F, lb.offsets, E, epilogue=L.EPI_ACTGRAD, act=tab.act,
                               aux=hpre if hpre is not None else hact)
         pg = [None] * ctx.n_params
-        if any(ctx.needs_input_grad[8:]):
+        if any(ctx.needs_input_grad[9:]):
             es = torch.tensor([], dtype=pd).element_size()
 
             def table(buf):
@@ -232,9 +323,13 @@ class EPFFN(torch.autograd.Function):
         dx2 = None
         if ctx.needs_input_grad[0]:
             dxs_s = ops.grouped_gemm(dh, tab.w1_ptrs, L.B_KN, tab.D, tab.D, lb.offsets, E)
-            dxs = a2a_rows(ops.dispatch_rows(dxs_s, _Unsort(lb)), plan.recv_splits, plan.send_splits, group)
+            if ctx.direct:
+                dxs = torch.empty(bins.n, dxs_s.shape[1], dtype=dxs_s.dtype, device=dev)
+                exchange_direct(direct_views(dxs, plan, 0, El, False), direct_views(dxs_s, plan, 0, El, True), group).wait()
+            else:
+                dxs = a2a_rows(ops.dispatch_rows(dxs_s, _Unsort(lb)), plan.recv_splits, plan.send_splits, group)
             dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
-        return (dx2, dw, None, None, None, None, None, None, *pg)
+        return (dx2, dw, None, None, None, None, None, None, None, *pg)
 
 
 class EPFFNChunked(torch.autograd.Function):
@@ -242,7 +337,7 @@ class EPFFNChunked(torch.autograd.Function):
     Same numbers as EPFFN: every row goes through the same kernels with the same operands, only the launch grouping differs."""
 
     @staticmethod
-    def forward(ctx, x2, w, idx, tab: ExpertTable, E_global: int, group, combine_mode: int, chunks: int, *params):
+    def forward(ctx, x2, w, idx, tab: ExpertTable, E_global: int, group, combine_mode: int, chunks: int, direct: bool, *params):
         x2 = x2.contiguous()
         T = x2.shape[0]
         bins = ops.bin_tokens(idx, E_global)
@@ -252,7 +347,10 @@ class EPFFNChunked(torch.autograd.Function):
         recvs, works = [], []
         for cp in cps:                                   # every outbound exchange is queued now, on the process group's stream
             r = torch.empty(cp.R, xs.shape[1], dtype=xs.dtype, device=xs.device)
-            works.append(exchange_views(_packed_views(r, cp.recv_n), _views(xs, cp.send_lo, cp.send_n), group))
+            if direct:
+                works.append(exchange_direct(direct_views(r, plan, cp.e0, cp.e1, True), direct_views(xs, plan, cp.e0, cp.e1, False), group))
+            else:
+                works.append(exchange_views(_packed_views(r, cp.recv_n), _views(xs, cp.send_lo, cp.send_n), group))
             recvs.append(r)
         y = torch.empty(bins.n, tab.Dout, dtype=xs.dtype, device=xs.device)
         back, keep, saved = [], [], []
@@ -260,16 +358,23 @@ class EPFFNChunked(torch.autograd.Function):
             with ops._timed("ep_wait_exposed"):
                 wk.wait()
             Ec = cp.e1 - cp.e0
-            lb = ops.bin_tokens(local_expert_ids(plan, cp.e0, cp.e1).view(-1, 1), Ec)
-            rs = ops.dispatch_rows(r, lb)
+            if direct:
+                lb, rs = local_bins(plan, cp.e0, cp.e1), r
+            else:
+                lb = ops.bin_tokens(local_expert_ids(plan, cp.e0, cp.e1).view(-1, 1), Ec)
+                rs = ops.dispatch_rows(r, lb)
             hpre, hact = ops.grouped_gemm(rs, tab.w1_ptrs[cp.e0:cp.e1], tab.layout, tab.D, tab.F, lb.offsets, Ec,
                                           bias_ptrs=None if tab.b1_ptrs is None else tab.b1_ptrs[cp.e0:cp.e1],
                                           epilogue=L.EPI_BIAS_ACT, act=tab.act, want_c2=True, want_c=tab.act != L.ACT_RELU)
             ys = ops.grouped_gemm(hact, tab.w2_ptrs[cp.e0:cp.e1], tab.layout, tab.F, tab.Dout, lb.offsets, Ec,
                                   bias_ptrs=None if tab.b2_ptrs is None else tab.b2_ptrs[cp.e0:cp.e1],
                                   epilogue=L.EPI_BIAS if tab.b2_ptrs is not None else L.EPI_PLAIN)
-            ret = ops.dispatch_rows(ys, _Unsort(lb))
-            back.append(exchange_views(_views(y, cp.send_lo, cp.send_n), _packed_views(ret, cp.recv_n), group))
+            if direct:
+                ret = ys
+                back.append(exchange_direct(direct_views(y, plan, cp.e0, cp.e1, False), direct_views(ret, plan, cp.e0, cp.e1, True), group))
+            else:
+                ret = ops.dispatch_rows(ys, _Unsort(lb))
+                back.append(exchange_views(_views(y, cp.send_lo, cp.send_n), _packed_views(ret, cp.recv_n), group))
             keep.append(ret)                             # alive until the return trip has been waited for
             saved.append((lb, rs, hpre, hact))
         with ops._timed("ep_wait_exposed"):
@@ -279,6 +384,7 @@ class EPFFNChunked(torch.autograd.Function):
         out = ops.combine(y, bins, idx, w, combine_mode, T)
         ctx.saved = (bins, plan, cps, saved, y)
         ctx.tab, ctx.w, ctx.group, ctx.n_params = tab, w, group, len(params)
+        ctx.direct = direct
         return out
 
     @staticmethod
@@ -292,13 +398,17 @@ class EPFFNChunked(torch.autograd.Function):
         assert tab.layout == L.B_NK
         E, dev, pd = tab.E, dout.device, tab.param_dtype
         T = dout.shape[0]
-        need_params = any(ctx.needs_input_grad[8:])
+        need_params = any(ctx.needs_input_grad[9:])
         need_dx = ctx.needs_input_grad[0]
+        direct = ctx.direct
         dy, dw = ops.combine_bwd(dout.contiguous(), y, bins, ctx.w, want_dw=ctx.needs_input_grad[1])
         recvs, works = [], []
         for cp in cps:
             r = torch.empty(cp.R, dy.shape[1], dtype=dy.dtype, device=dev)
-            works.append(exchange_views(_packed_views(r, cp.recv_n), _views(dy, cp.send_lo, cp.send_n), group))
+            if direct:
+                works.append(exchange_direct(direct_views(r, plan, cp.e0, cp.e1, True), direct_views(dy, plan, cp.e0, cp.e1, False), group))
+            else:
+                works.append(exchange_views(_packed_views(r, cp.recv_n), _views(dy, cp.send_lo, cp.send_n), group))
             recvs.append(r)
         gW1 = gW2 = gb1 = gb2 = None
         if need_params:
@@ -323,13 +433,17 @@ class EPFFNChunked(torch.autograd.Function):
                 wk.wait()
             e0, e1 = cp.e0, cp.e1
             Ec = e1 - e0
-            dys = ops.dispatch_rows(r, lb)
+            dys = r if direct else ops.dispatch_rows(r, lb)
             dh = ops.grouped_gemm(dys, tab.w2_ptrs[e0:e1], L.B_KN, tab.F, tab.F, lb.offsets, Ec, epilogue=L.EPI_ACTGRAD, act=tab.act,
                                   aux=hpre if hpre is not None else hact)
             if need_dx:                                  # input gradient first: its return trip overlaps this group's weight gradients
                 dxs_s = ops.grouped_gemm(dh, tab.w1_ptrs[e0:e1], L.B_KN, tab.D, tab.D, lb.offsets, Ec)
-                ret = ops.dispatch_rows(dxs_s, _Unsort(lb))
-                back.append(exchange_views(_views(dxs, cp.send_lo, cp.send_n), _packed_views(ret, cp.recv_n), group))
+                if direct:
+                    ret = dxs_s
+                    back.append(exchange_direct(direct_views(dxs, plan, e0, e1, False), direct_views(ret, plan, e0, e1, True), group))
+                else:
+                    ret = ops.dispatch_rows(dxs_s, _Unsort(lb))
+                    back.append(exchange_views(_views(dxs, cp.send_lo, cp.send_n), _packed_views(ret, cp.recv_n), group))
                 keep.append(ret)
             if need_params:
                 ops.grouped_wgrad(dys, hact, lb.offsets, Ec, gW2, tW2[e0:e1], xcd_order=lb.xcd_order)
@@ -349,7 +463,7 @@ class EPFFNChunked(torch.autograd.Function):
                     wk.wait()
             del keep
             dx2 = ops.dispatch_rows_bwd(dxs, bins, T)
-        return (dx2, dw, None, None, None, None, None, None, *pg)
+        return (dx2, dw, None, None, None, None, None, None, None, *pg)
 
 
 def reduce_grad_on_backward(param: torch.Tensor, group=None):
@@ -373,12 +487,15 @@ class EPSMoeLayer(MoeLayer):
     group after backward (tokens are data-parallel); expert gradients are local by construction."""
 
     def __init__(self, in_embed_dim=768, out_embed_dim=768, num_of_experts=4, num_selected=2, expert=None, args=None, group=None,
-                 chunks: Optional[int] = None):
+                 chunks: Optional[int] = None, direct: Optional[bool] = None):
         if not isinstance(expert, nn.ModuleList):
             raise ValueError("EPSMoeLayer: pass this rank's local experts as an nn.ModuleList")
         super().__init__(in_embed_dim, out_embed_dim, num_of_experts, num_selected, expert, args)
         self.group = group
         self.chunks = chunks        # groups of local experts whose exchanges overlap the GEMMs; None: CSMOE_EP_CHUNKS, else 2 (1 at P=1)
+        # one message per (peer, local expert) instead of one per peer + regroup passes (exchange_direct); None: CSMOE_EP_DIRECT, else
+        # off -- the per-peer exchange is the form that has run on more than one rank of real hardware least untested (DESIGN section 5)
+        self.direct = direct
         self.init_gate_weights()
         reduce_grad_on_backward(self.gate.weight, group)
 
@@ -397,10 +514,12 @@ class EPSMoeLayer(MoeLayer):
         chunks = self._n_chunks()
         w2 = weights.reshape(B * N, weights.shape[-1]).contiguous()
         i2 = selected_experts.reshape(B * N, selected_experts.shape[-1]).contiguous()
+        direct = _direct_default() if self.direct is None else bool(self.direct)
         if chunks > 1:
-            out = EPFFNChunked.apply(x.reshape(B * N, D), w2, i2, tab, self.num_of_experts, self.group, L.COMBINE_SEQ, chunks, *params)
+            out = EPFFNChunked.apply(x.reshape(B * N, D), w2, i2, tab, self.num_of_experts, self.group, L.COMBINE_SEQ, chunks, direct,
+                                     *params)
         else:
-            out, _ = EPFFN.apply(x.reshape(B * N, D), w2, i2, tab, self.num_of_experts, self.group, L.COMBINE_SEQ, False, *params)
+            out, _ = EPFFN.apply(x.reshape(B * N, D), w2, i2, tab, self.num_of_experts, self.group, L.COMBINE_SEQ, False, direct, *params)
         output = out.view(B, N, out.shape[-1])
         auxiliary_loss = x.new_zeros(())        # a fill kernel: torch.tensor(0.0, device=...) is a blocking H2D copy
         infor_aux = {}
@@ -503,7 +622,7 @@ class EPCompeteSMoE(MoeLayer):
         tab, params = self._expert_table(len(self.experts), x.dtype, x.device)
         K = idx.shape[-1]
         out, y_tk = EPFFN.apply(x.reshape(B * N, D), w.reshape(B * N, K).float().contiguous(), idx.reshape(B * N, K).int().contiguous(),
-                                tab, self.num_of_experts, self.group, mode, want_slots, *params)
+                                tab, self.num_of_experts, self.group, mode, want_slots, _direct_default(), *params)
         return out.view(B, N, -1), (y_tk.view(B, N, K, -1) if want_slots else None)
 
     def competition_policy(self, x):

@@ -64,6 +64,24 @@ def _worker(rank, world, port, T, D, E, K, q):
                 ret = r * (gid_c + 1).unsqueeze(1).float()
                 ep.exchange_views(ep._views(y2, cp.send_lo, cp.send_n), ep._packed_views(ret, cp.recv_n)).wait()
             ok = ok and torch.equal(y2, exp)
+        # direct exchange: one message per (peer, local expert) straight into an expert-major buffer -- the rows the regroup pass
+        # would have produced (stable by source rank inside an expert), offsets from the counts, and the way back; whole and in groups
+        want = recv[torch.sort(ids.long(), stable=True).indices]
+        for chunks in (1, 2, El):
+            cps = ep.chunk_plan(plan2, chunks)
+            y3 = torch.full_like(xs, float("nan"))
+            got = []
+            for cp in cps:
+                r = torch.empty(cp.R, D)
+                ep.exchange_direct(ep.direct_views(r, plan2, cp.e0, cp.e1, True), ep.direct_views(xs, plan2, cp.e0, cp.e1, False)).wait()
+                lb = ep.local_bins(plan2, cp.e0, cp.e1)
+                off = lb.offsets.long()
+                assert int(off[-1]) == cp.R == lb.n and torch.equal(off[1:] - off[:-1], plan2.recv_counts[:, cp.e0:cp.e1].sum(0).long())
+                got.append(r)
+                gid_c = torch.repeat_interleave(torch.arange(cp.e1 - cp.e0), off[1:] - off[:-1]) + cp.e0 + rank * El
+                ret = r * (gid_c + 1).unsqueeze(1).float()
+                ep.exchange_direct(ep.direct_views(y3, plan2, cp.e0, cp.e1, False), ep.direct_views(ret, plan2, cp.e0, cp.e1, True)).wait()
+            ok = ok and torch.equal(torch.cat(got), want) and torch.equal(y3, exp)
         # all ranks' counts line up: recv_counts[s] == rank s's send counts for my experts
         allc = [torch.zeros(E, dtype=torch.int32) for _ in range(world)]
         dist.all_gather(allc, counts.int())

@@ -48,6 +48,17 @@ def _run(rank, world, port, backend, dt_name, q, chunks=1, empty_half=False):
                 real(o, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
                 out.copy_(o)
             dist.all_to_all_single = via_host
+            real_direct = ep.exchange_direct
+
+            def direct_via_host(dst, src, group=None):       # gloo moves host tensors: stage the (peer, expert) messages through the host
+                src_h = [(p_, v.cpu()) for p_, v in src]
+                dst_h = [(p_, torch.empty(v.shape, dtype=v.dtype)) for p_, v in dst]
+                real_direct(dst_h, src_h, group).wait()
+                for (_, d_), (_, h_) in zip(dst, dst_h):
+                    if d_.shape[0]:
+                        d_.copy_(h_)
+                return ep._Works([])
+            ep.exchange_direct = direct_via_host
         dt = torch.float32 if dt_name == "fp32" else torch.bfloat16
         B, N, D, F, E, K = 2, 96, 64, 128, 8, 2
         args = types.SimpleNamespace(balance_loss_coef=0.01, router_z_loss_coef=0.001)
@@ -228,6 +239,17 @@ def test_ep_world4_one_gpu_equals_single_gpu(dt_name, chunks):
     all-reduced single-GPU ones, replicated gate gradient summed over the ranks.  (More ranks than this on one card are not allowed
     on the test box; the exchange plumbing alone runs at 8 ranks in tests/test_ep_gloo.py.)"""
     assert _launch(4, "gloo", dt_name, chunks) == {r: True for r in range(4)}
+
+
+@pytest.mark.parametrize("world,backend,dt_name,chunks,empty_half",
+                         [(1, "nccl", "bf16", 1, False), (1, "nccl", "bf16", 3, False), (2, "gloo", "fp32", 1, False),
+                          (2, "gloo", "bf16", 2, False), (4, "gloo", "bf16", 2, False), (2, "gloo", "fp32", 2, True), (1, "nccl", "fp32", 2, True)])
+def test_ep_direct_exchange_equals_single_gpu(world, backend, dt_name, chunks, empty_half, monkeypatch):
+    """CSMOE_EP_DIRECT=1: one message per (peer, local expert) delivered expert-major (no regroup pass, no inverse before the return
+    trip), plain and in overlapped groups, over RCCL at world 1 (self pair = device copies) and through gloo at worlds 2 and 4 on one
+    GPU, with experts (and at world 2 a whole rank) that receive nothing: the same bits as the single-GPU layer."""
+    monkeypatch.setenv("CSMOE_EP_DIRECT", "1")
+    assert _launch(world, backend, dt_name, chunks, empty_half) == {r: True for r in range(world)}
 
 
 @pytest.mark.parametrize("world,backend,chunks", [(1, "nccl", 1), (1, "nccl", 2), (2, "gloo", 1), (2, "gloo", 2)])
