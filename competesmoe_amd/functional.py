@@ -515,6 +515,8 @@ def _ffn_backward(dout, w, tab: ExpertTable, saved, need_dx: bool, need_dw: bool
             dx2 = dx2 + pre_lost
     elif handoff is not None:
         handoff.routed_done = True
+        if handoff.dx is not None:                     # the always-on expert already handed its dx over: it must not be dropped
+            dx2, handoff.dx = handoff.dx, None
     return dx2, dw, grads
 
 
