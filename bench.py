@@ -148,15 +148,16 @@ def make_layer(a, dev, dt, E_local=None, seed=1):
     return layer
 
 
-def make_pretrain_layer(a, dev):
-    """pretrain-stack `smoe` (moe_pretrain_model/layers/moe/smoe.py): fp32 master parameters, the step runs under bf16 autocast."""
+def make_pretrain_layer(a, dev, ep=False):
+    """pretrain-stack `smoe` (moe_pretrain_model/layers/moe/smoe.py): fp32 master parameters, the step runs under bf16 autocast.
+    `ep`: the expert-parallel form `smoe_ep` (this rank's E/P experts of the packed tensors; competesmoe_amd/pretrain/smoe_ep.py)."""
     import torch.nn.functional as F
     from competesmoe_amd.pretrain import get_moe
     args = types.SimpleNamespace(moe_name="smoe", stop_after=10, warm_up=0.0, rate_flip=1.0, max_compete_in_iter=8,
                                  balance_loss_coef=0.01, balance_loss_coef_comp=0.02, router_loss_coef=0.03, router_theta=0.5,
                                  in_topk=False, hybrid=False, tribrid=False, balance_affinity=False, is_cosine=False,
                                  is_norm_weight=False, norm_sigmoid=False, scale_weight=1.0, test_only=False)
-    name = "smoe"
+    name = "smoe_ep" if ep else "smoe"
     if a.dtype == "fp8" or a.shared > 0:
         name = "deepseekv2" if a.shared > 0 else "smoe"
         args.fp8_experts = a.dtype == "fp8"
@@ -344,8 +345,11 @@ def main():
     Bsz = max(1, T // a.seq)
     Nseq = T // Bsz
     if a.stack == "pretrain":
-        assert world == 1 and not (a.force_ep or a.competition), "--stack pretrain: single-GPU smoe step (optionally --block) only"
-        layer = make_pretrain_layer(a, dev)
+        ep_pre = world > 1 or a.force_ep
+        assert not a.competition and not (ep_pre and (a.dtype == "fp8" or a.shared > 0)), \
+            "--stack pretrain: the smoe step (optionally --block; expert-parallel over the ranks), or the single-GPU fp8 / shared-expert layer"
+        assert a.experts % world == 0, "experts must divide over ranks"
+        layer = make_pretrain_layer(a, dev, ep=ep_pre)
         if a.weight_cache:
             from competesmoe_amd import functional as Fn
             Fn.weight_cache(True)

@@ -466,6 +466,241 @@ class EPFFNChunked(torch.autograd.Function):
         return (dx2, dw, None, None, None, None, None, None, None, *pg)
 
 
+# ------------------------------------------------------------------------------------------------ packed experts (pretrain stack)
+class _Lane:
+    """One group [e0, e1) of local experts of an exchange: carries rows of the token side's binned row space to their owners, where
+    they stand expert-major, and rows back (per-peer messages + a regroup pass, or `direct`).  Narrow fp32 columns ([n, 1]: routing
+    weights out, dot products back) take the same road with torch indexing as their regroup."""
+
+    def __init__(self, plan: EPPlan, cp: EPChunk, direct: bool, group):
+        self.plan, self.cp, self.direct, self.group = plan, cp, direct, group
+        self._lb = None
+
+    @property
+    def lb(self) -> "ops.Bins":
+        if self._lb is None:
+            cp = self.cp
+            self._lb = (local_bins(self.plan, cp.e0, cp.e1) if self.direct else
+                        ops.bin_tokens(local_expert_ids(self.plan, cp.e0, cp.e1).view(-1, 1), cp.e1 - cp.e0))
+        return self._lb
+
+    def send(self, src: torch.Tensor):
+        """token side -> owners, asynchronously: (receive buffer, handle)."""
+        cp = self.cp
+        r = torch.empty(cp.R, src.shape[1], dtype=src.dtype, device=src.device)
+        if self.direct:
+            wk = exchange_direct(direct_views(r, self.plan, cp.e0, cp.e1, True), direct_views(src, self.plan, cp.e0, cp.e1, False), self.group)
+        else:
+            wk = exchange_views(_packed_views(r, cp.recv_n), _views(src, cp.send_lo, cp.send_n), self.group)
+        return r, wk
+
+    def arrived(self, r: torch.Tensor) -> torch.Tensor:
+        """A waited-for receive buffer as expert-major rows."""
+        if self.direct or r.shape[0] == 0:
+            return r
+        return r[self.lb.perm.long()] if r.shape[1] == 1 else ops.dispatch_rows(r, self.lb)
+
+    def give_back(self, rows: torch.Tensor, dst: torch.Tensor):
+        """owners -> token side, asynchronously, into the binned row space `dst`: (handle, buffer to keep alive until waited for)."""
+        cp = self.cp
+        if self.direct:
+            return exchange_direct(direct_views(dst, self.plan, cp.e0, cp.e1, False), direct_views(rows, self.plan, cp.e0, cp.e1, True),
+                                   self.group), rows
+        if rows.shape[0]:
+            rows = rows[self.lb.slot_of.long()] if rows.shape[1] == 1 else ops.dispatch_rows(rows, _Unsort(self.lb))
+        return exchange_views(_views(dst, cp.send_lo, cp.send_n), _packed_views(rows, cp.recv_n), self.group), rows
+
+
+class EPFFNPacked(torch.autograd.Function):
+    """functional.MoEFFNPacked (the pretrain stack's two `cvmm` calls, moe_pretrain_model/layers/moe/moe.py:397-435 + cvmm.py:490-551)
+    with the packed experts sharded over the group: `keys` [E/P, D, F], `values` [E/P, F, Dout] (+ `bias` [E/P, F]) are THIS rank's
+    experts, `idx` holds global expert ids.  Rows travel to their experts' owners in `chunks` groups of local experts whose exchanges
+    overlap the grouped GEMMs, as in EPFFNChunked.  The arithmetic is the single-GPU function's, row for row:
+    * forward: combine with the bf16-valued routing weights (`reduction_weight.type_as`), o_bias / residual in its epilogue;
+    * backward of the weighted product in the reference's order (cvmm.py:527-543): the UNSCALED upstream rows and their routing
+      weights go to the owners, where dH's epilogue scales the rounded product; the owners form dy = round(w * row) for d values
+      themselves; with ReLU experts d w is the dot <unscaled rounded product, activated input> (cvmm.py:544) out of the same launch
+      and returns with the dXs rows as one fp32 column."""
+
+    @staticmethod
+    def forward(ctx, x2, w, idx, keys, values, bias, o_bias, act: int, combine_mode: int, E_global: int, group, chunks: int,
+                direct: bool, residual=None, stats=None):
+        from . import functional as Fn
+        x2 = x2.contiguous()
+        op = x2.dtype
+        if op == torch.bfloat16:
+            w = w.to(op).float()
+        El, D, F = keys.shape
+        Dout = values.shape[2]
+        dev = x2.device
+        T = x2.shape[0]
+
+        def operand(t):
+            if t.dtype == op:
+                return t.contiguous()
+            if Fn._WEIGHT_CACHE_ON:
+                c, hit = Fn._cached_copy(t, op)
+                if hit:
+                    return c
+            c = t.to(op)
+            if Fn._WEIGHT_CACHE_ON:
+                Fn._remember(t, op, c)
+            return c
+
+        # fp32 masters under bf16 rows: converted inside the forward GEMMs' tile fill, the bf16 copies the backward reads being a side
+        # output (functional.MoEFFNPacked; groups too small for that kernel cast their slice first)
+        in_fill = (Fn._F32W_ON and not Fn._WEIGHT_CACHE_ON and op == torch.bfloat16 and keys.dtype == torch.float32
+                   and values.dtype == torch.float32 and keys.is_contiguous() and values.is_contiguous())
+        if in_fill:
+            k_op = torch.empty(keys.shape, dtype=op, device=dev)
+            v_op = torch.empty(values.shape, dtype=op, device=dev)
+        else:
+            k_op, v_op = operand(keys), operand(values)
+        es = k_op.element_size()
+        b_op = b1 = None
+        epi1 = L.EPI_BIAS_ACT
+        if bias is not None and bias.dtype == torch.float32 and op == torch.bfloat16:
+            b_op = bias.contiguous()
+            b1 = ops.ptr_table(b_op, El, F * 4)
+            epi1 = L.EPI_ROUND_BIAS32_ACT
+        elif bias is not None:
+            b_op = bias.contiguous() if bias.dtype == op else bias.to(op)
+            b1 = ops.ptr_table(b_op, El, F * es)
+        ob = None
+        if o_bias is not None:
+            ob = o_bias.contiguous() if o_bias.dtype == op else o_bias.to(op)
+        tab = ExpertTable(E=El, D=D, F=F, Dout=Dout, layout=L.B_KN, act=act, w1_ptrs=ops.ptr_table(k_op, El, D * F * es),
+                          w2_ptrs=ops.ptr_table(v_op, El, F * Dout * es), b1_ptrs=b1, b2_ptrs=None, param_dtype=keys.dtype, epi1=epi1,
+                          scale_after_gemm=combine_mode == L.COMBINE_DOT)
+        bins = ops.bin_tokens(idx, E_global)
+        xs = ops.dispatch_tokens(x2, bins)
+        plan = make_plan(bins.counts, group, per_expert=True)
+        lanes = [_Lane(plan, cp, direct, group) for cp in chunk_plan(plan, chunks)]
+        sent = [ln.send(xs) for ln in lanes]               # every outbound exchange is queued now, on the process group's stream
+        y = torch.empty(bins.n, Dout, dtype=op, device=dev)
+        back, saved = [], []
+        for ln, (r, wk) in zip(lanes, sent):
+            with ops._timed("ep_wait_exposed"):
+                wk.wait()
+            e0, e1 = ln.cp.e0, ln.cp.e1
+            rs, lb = ln.arrived(r), ln.lb
+            b1c = None if b1 is None else b1[e0:e1]
+            if in_fill and ops.f32w_ok(rs.shape[0], F, D) and ops.f32w_ok(rs.shape[0], Dout, F):
+                hpre, hact = ops.grouped_gemm_f32w(rs, keys[e0:e1], lb.offsets, copy=k_op[e0:e1], bias_ptrs=b1c, epilogue=epi1, act=act,
+                                                   want_c2=True, want_c=act != L.ACT_RELU)
+                ys = ops.grouped_gemm_f32w(hact, values[e0:e1], lb.offsets, copy=v_op[e0:e1])
+            else:
+                if in_fill:
+                    k_op[e0:e1].copy_(keys[e0:e1])
+                    v_op[e0:e1].copy_(values[e0:e1])
+                hpre, hact = ops.grouped_gemm(rs, tab.w1_ptrs[e0:e1], L.B_KN, F, F, lb.offsets, e1 - e0, bias_ptrs=b1c, epilogue=epi1,
+                                              act=act, want_c2=True, want_c=act != L.ACT_RELU)
+                ys = ops.grouped_gemm(hact, tab.w2_ptrs[e0:e1], L.B_KN, Dout, Dout, lb.offsets, e1 - e0)
+            back.append(ln.give_back(ys, y))
+            saved.append((rs, hpre, hact))
+        with ops._timed("ep_wait_exposed"):
+            for wk, _ in back:
+                wk.wait()
+        del back, sent
+        out = ops.combine(y, bins, idx, w, combine_mode, T, obias=ob, residual=None if residual is None else residual.contiguous())
+        if stats is not None:               # `relu_pass_rate` over the rows this rank's experts processed
+            stats["hact"] = torch.cat([sv[2] for sv in saved]) if len(saved) > 1 else saved[0][2]
+        ctx.tab, ctx.w, ctx.group, ctx.op = tab, w, group, op
+        ctx.saved = (bins, lanes, saved, y)
+        ctx.keep = (k_op, v_op, b_op)
+        ctx.has = (bias is not None, o_bias is not None, residual is not None)
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        ctx.ob_dtype = None if o_bias is None else o_bias.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import functional as Fn
+        if ctx.saved is None:
+            raise RuntimeError("competesmoe_amd: saved activations were freed by the first backward pass; a second backward "
+                               "through the same graph (retain_graph=True) is not supported -- run the forward again")
+        bins, lanes, saved, y = ctx.saved
+        ctx.saved = None
+        tab, op = ctx.tab, ctx.op
+        El, D, F, Dout, pd = tab.E, tab.D, tab.F, tab.Dout, tab.param_dtype
+        dev = dout.device
+        T = dout.shape[0]
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_params = ctx.needs_input_grad[3] or ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+        dout = dout.contiguous()
+        scale_after = tab.scale_after_gemm and Fn._SCALE_AFTER_ON
+        relu = tab.act == L.ACT_RELU
+        # every rank must take the same road (the dot column is an exchange): decided from the shapes, not from this rank's row count
+        use_dot = bool(scale_after and need_dw and relu and ops.rowdot_cols(256, F, Dout, Dout, Dout, F, op) > 0)
+        dy, dw = ops.combine_bwd(dout, y if (need_dw and not use_dot) else None, bins, ctx.w, want_dw=need_dw and not use_dot, act_dtype=op)
+        del y
+        if scale_after:
+            rows_out = ops.dispatch_tokens(dout.to(op), bins)
+            w_out = ctx.w.reshape(-1)[bins.perm.long()].float().view(-1, 1).contiguous()
+            sent = [(ln.send(rows_out), ln.send(w_out)) for ln in lanes]
+        else:
+            sent = [(ln.send(dy), None) for ln in lanes]
+        gk = gv = gb = None
+        if need_params:
+            es = torch.tensor([], dtype=pd).element_size()
+            gk = torch.empty(El, D, F, dtype=pd, device=dev)
+            gv = torch.empty(El, F, Dout, dtype=pd, device=dev)
+            tk, tv = ops.ptr_table(gk, El, D * F * es), ops.ptr_table(gv, El, F * Dout * es)
+            if tab.b1_ptrs is not None:
+                gb = torch.empty(El, F, dtype=pd, device=dev)
+                tb = ops.ptr_table(gb, El, F * es)
+        dxs = torch.empty(bins.n, D, dtype=op, device=dev) if need_dx else None
+        dots = torch.empty(bins.n, 1, dtype=torch.float32, device=dev) if use_dot else None
+        back = []
+        for ln, (rows_s, w_s), (rs, hpre, hact) in zip(lanes, sent, saved):
+            with ops._timed("ep_wait_exposed"):
+                rows_s[1].wait()
+                if w_s is not None:
+                    w_s[1].wait()
+            e0, e1 = ln.cp.e0, ln.cp.e1
+            Ec, lb = e1 - e0, ln.lb
+            dys = ln.arrived(rows_s[0])
+            aux = hpre if hpre is not None else hact
+            if scale_after:
+                wr = ln.arrived(w_s[0]).view(-1)
+                dot = None
+                if use_dot and dys.shape[0]:
+                    dc = ops.rowdot_cols(dys.shape[0], F, Dout, Dout, Dout, F, op)
+                    if dc == 0:
+                        raise RuntimeError("competesmoe_amd: EPFFNPacked: this rank's dH launch writes no dot table while the group's does")
+                    dot = torch.empty(dys.shape[0], dc, dtype=torch.float32, device=dev)
+                dh = ops.grouped_gemm(dys, tab.w2_ptrs[e0:e1], L.B_NK, Dout, F, lb.offsets, Ec, epilogue=L.EPI_ACTGRAD_ROWSCALE, act=tab.act,
+                                      aux=aux, row_scale=wr, row_dot=dot)
+                if use_dot:
+                    col = ops.finish_row_dot(dot).view(-1, 1) if dot is not None else torch.empty(0, 1, dtype=torch.float32, device=dev)
+                    back.append(ln.give_back(col, dots))
+                if need_params:                          # dy = round(w * upstream row), what combine_bwd hands the single-GPU d values
+                    dys = (dys.float() * wr.view(-1, 1)).to(op)
+            else:
+                dh = ops.grouped_gemm(dys, tab.w2_ptrs[e0:e1], L.B_NK, Dout, F, lb.offsets, Ec, epilogue=L.EPI_ACTGRAD, act=tab.act, aux=aux)
+            if need_dx:                                  # input gradient first: its return trip overlaps this group's weight gradients
+                back.append(ln.give_back(ops.grouped_gemm(dh, tab.w1_ptrs[e0:e1], L.B_NK, F, D, lb.offsets, Ec), dxs))
+            if need_params:
+                ops.grouped_wgrad(hact, dys, lb.offsets, Ec, gv, tv[e0:e1], xcd_order=lb.xcd_order)
+                ops.grouped_wgrad(rs, dh, lb.offsets, Ec, gk, tk[e0:e1], xcd_order=lb.xcd_order)
+                if gb is not None:
+                    ops.grouped_colsum(dh, lb.offsets, Ec, gb, tb[e0:e1])
+        with ops._timed("ep_wait_exposed"):
+            for wk, _ in back:
+                wk.wait()
+        del back, sent
+        if use_dot:
+            dw = dots.view(-1)[bins.slot_of.long()].view(T, bins.K)
+        dx2 = ops.dispatch_rows_bwd(dxs, bins, T) if need_dx else None
+        if gb is not None and gb.dtype != ctx.bias_dtype:
+            gb = gb.to(ctx.bias_dtype)
+        gob = None
+        if ctx.has[1] and ctx.needs_input_grad[6]:
+            gob = Fn._chunked_dense_colsum(dout, ctx.ob_dtype)
+        return (dx2, dw, None, gk, gv, gb, gob, None, None, None, None, None, None,
+                dout if (ctx.has[2] and ctx.needs_input_grad[13]) else None, None)
+
+
 def reduce_grad_on_backward(param: torch.Tensor, group=None):
     """Sum the gradient of a REPLICATED parameter over the expert-parallel group, once per backward pass, BEFORE it is
     accumulated into `param.grad`: with gradient accumulation (several micro-batches per optimizer step -- the pretrain loop,

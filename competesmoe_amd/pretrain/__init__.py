@@ -8,6 +8,7 @@ from .competesmoe import CompeteSMoE
 from .deepseek import DeepSeekV2, DeepSeekV3
 from .smoe_perturbed import MoEPerturbedCosingGating, Selection
 from .block import MoEBlock
+from .smoe_ep import EPSMoeLayer
 
 __all__ = ["register_moe", "get_moe", "MOE_REGISTRY", "LoggingLayer", "RegularizedLayer", "OncePerIterLayer", "CVMMSel", "cvmm",
-           "cvmm_prepare_sel2", "MoE", "SMoeLayer", "CompeteSMoE", "DeepSeekV2", "DeepSeekV3", "MoEPerturbedCosingGating", "Selection", "MoEBlock"]
+           "cvmm_prepare_sel2", "MoE", "SMoeLayer", "CompeteSMoE", "DeepSeekV2", "DeepSeekV3", "MoEPerturbedCosingGating", "Selection", "MoEBlock", "EPSMoeLayer"]

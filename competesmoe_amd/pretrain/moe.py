@@ -98,13 +98,14 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         else:
             self.w_gate = nn.Parameter(torch.empty(n_experts, dmodel))
             nn.init.normal_(self.w_gate, std=dmodel ** -0.5 * weight_scale)
-            self.values = nn.Parameter(torch.empty(n_experts, expert_size, self.v_dim))
-            self.keys = nn.Parameter(torch.empty(n_experts, dmodel, expert_size))
+            n_held = self._n_held_experts(n_experts)     # expert-parallel layers hold their own slice of the packed tensors only
+            self.values = nn.Parameter(torch.empty(n_held, expert_size, self.v_dim))
+            self.keys = nn.Parameter(torch.empty(n_held, dmodel, expert_size))
             nn.init.normal_(self.keys, std=dmodel ** -0.5 * weight_scale)
             nn.init.normal_(self.values, std=self.size ** -0.5 * weight_scale)
             self.num_selected = n_heads      # "with MLP we get number of expert is n_head" (moe.py:128)
         if bias:
-            self.bias = nn.Parameter(torch.zeros(n_experts, expert_size))
+            self.bias = nn.Parameter(torch.zeros(self._n_held_experts(n_experts), expert_size))
             self.o_bias = nn.Parameter(torch.zeros(self.v_dim))
         else:
             self.bias = None
@@ -118,6 +119,10 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         self._stream_dtype = None     # dtype of the tensor the reference layer would have been called with (its `x.dtype`)
 
     _fuses_residual = False           # True on layers whose output IS one combine (smoe, competesmoe)
+
+    def _n_held_experts(self, n_experts: int) -> int:
+        """Experts whose weights this module holds (all of them; pretrain/smoe_ep.py: this rank's share)."""
+        return n_experts
 
     def _plain_gate(self) -> bool:
         """compute_gate is F.linear(x, w_gate) (what the block's fused LayerNorm + gate launch computes)."""

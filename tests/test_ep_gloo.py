@@ -82,6 +82,35 @@ def _worker(rank, world, port, T, D, E, K, q):
                 ret = r * (gid_c + 1).unsqueeze(1).float()
                 ep.exchange_direct(ep.direct_views(y3, plan2, cp.e0, cp.e1, False), ep.direct_views(ret, plan2, cp.e0, cp.e1, True)).wait()
             ok = ok and torch.equal(torch.cat(got), want) and torch.equal(y3, exp)
+        # the lanes of the packed (pretrain) exchange, ep._Lane: wide rows on the direct road, and the narrow fp32 column (routing
+        # weights out, dot products back) on both roads -- the per-peer road regroups a column by torch indexing with the lane's
+        # local binning (built by the HIP binning kernel in the product; by the oracle's here)
+        from competesmoe_amd import ops
+        col = torch.arange(xs.shape[0], dtype=torch.float32).view(-1, 1) + 1000.0 * rank
+        for direct in (True, False):
+            for chunks in (1, 2, El):
+                y4 = torch.full_like(xs, float("nan"))
+                c4 = torch.full_like(col, float("nan"))
+                for cp in ep.chunk_plan(plan2, chunks):
+                    ln = ep._Lane(plan2, cp, direct, None)
+                    Ec = cp.e1 - cp.e0
+                    if not direct:
+                        cn, of, pm = O.bin_tokens(ep.local_expert_ids(plan2, cp.e0, cp.e1).view(-1, 1), Ec)
+                        so = torch.empty_like(pm)
+                        so[pm.long()] = torch.arange(pm.numel(), dtype=pm.dtype)
+                        ln._lb = ops.Bins(cn, of, pm, so, int(pm.numel()), Ec, 1)
+                    off = ln.lb.offsets.long()
+                    gid_c = (torch.repeat_interleave(torch.arange(Ec), off[1:] - off[:-1]) + cp.e0 + rank * El + 1).view(-1, 1).float()
+                    rc, wk = ln.send(col)
+                    wk.wait()
+                    wk, _keep = ln.give_back(ln.arrived(rc) * gid_c, c4)
+                    wk.wait()
+                    if direct:
+                        rr, wk = ln.send(xs)
+                        wk.wait()
+                        wk, _keep = ln.give_back(ln.arrived(rr) * gid_c, y4)
+                        wk.wait()
+                ok = ok and torch.equal(c4, col * (e_sorted + 1).view(-1, 1).float()) and (not direct or torch.equal(y4, exp))
         # all ranks' counts line up: recv_counts[s] == rank s's send counts for my experts
         allc = [torch.zeros(E, dtype=torch.int32) for _ in range(world)]
         dist.all_gather(allc, counts.int())

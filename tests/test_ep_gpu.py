@@ -189,6 +189,121 @@ def _run_comp(rank, world, port, backend, dt_name, q, *unused):
         dist.destroy_process_group()
 
 
+def _run_pretrain(rank, world, port, backend, dt_name, q, chunks=1, empty_half=False):
+    """Pretrain `smoe_ep` against the single-GPU pretrain `smoe` on the same tokens.  dt_name: "fp32", "bf16" (bf16 autocast over fp32
+    masters: the stack's training configuration; ReLU experts, so d w comes out of the dH launch's dot epilogue), "bf16_bias"."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        import torch.nn.functional as F
+        from competesmoe_amd import ep
+        from competesmoe_amd.pretrain import get_moe
+        if backend == "gloo":
+            real = dist.all_to_all_single
+
+            def via_host(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+                o = torch.empty(out.shape, dtype=out.dtype)
+                real(o, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes, group=group)
+                out.copy_(o)
+            dist.all_to_all_single = via_host
+            real_direct = ep.exchange_direct
+
+            def direct_via_host(dst, src, group=None):
+                src_h = [(p_, v.cpu()) for p_, v in src]
+                dst_h = [(p_, torch.empty(v.shape, dtype=v.dtype)) for p_, v in dst]
+                real_direct(dst_h, src_h, group).wait()
+                for (_, d_), (_, h_) in zip(dst, dst_h):
+                    if d_.shape[0]:
+                        d_.copy_(h_)
+                return ep._Works([])
+            ep.exchange_direct = direct_via_host
+        bias = dt_name.endswith("_bias")
+        block = dt_name.endswith("_block")     # inside pretrain.MoEBlock: fp32 stream, fused LayerNorm + gate, residual in the combine
+        autocast = dt_name.startswith("bf16")
+        B, N, D, Fh, E, K = 2, 96, 64, 128, 8, 2
+        if dt_name.endswith("_big"):        # enough rows per group for the kernels that convert the fp32 masters in their tile fill
+            B, N, D, Fh = 4, 1024, 256, 256
+        args = types.SimpleNamespace(balance_loss_coef=0.01)
+        torch.manual_seed(11)
+        full = get_moe("smoe")(D, E, Fh, n_heads=K, activation=F.relu, bias=bias, args=args).to(dev).train()
+        if bias:
+            with torch.no_grad():
+                full.bias.normal_(0, 0.1)
+                full.o_bias.normal_(0, 0.1)
+        El = E // world
+        epl = get_moe("smoe_ep")(D, E, Fh, n_heads=K, activation=F.relu, bias=bias, args=args, chunks=chunks).to(dev).train()
+        assert tuple(epl.keys.shape) == (El, D, Fh) and tuple(epl.values.shape) == (El, Fh, D)
+        full.regularization_present = epl.regularization_present = True
+        with torch.no_grad():
+            epl.w_gate.copy_(full.w_gate)
+            epl.keys.copy_(full.keys[rank * El:(rank + 1) * El])
+            epl.values.copy_(full.values[rank * El:(rank + 1) * El])
+            if bias:
+                epl.bias.copy_(full.bias[rank * El:(rank + 1) * El])
+                epl.o_bias.copy_(full.o_bias)
+        g = torch.Generator().manual_seed(70 + rank)
+        x = torch.randn(B, N, D, generator=g)
+        if empty_half:
+            x[..., 0] = x[..., 0].abs() + 4.0
+            with torch.no_grad():
+                for lay in (full, epl):
+                    lay.w_gate[: E // 2, 0] = 1.0
+                    lay.w_gate[E // 2:, 0] = -1.0
+        x = x.to(dev)
+        dy = torch.randn(B, N, D, generator=g).to(dev)
+        xa = x.clone().requires_grad_(True)
+        xb = x.clone().requires_grad_(True)
+
+        mod_a, mod_b = full, epl
+        if block:
+            from competesmoe_amd.pretrain import MoEBlock
+            norms = [nn.LayerNorm(D).to(dev) for _ in range(2)]
+            with torch.no_grad():
+                for ln in norms:
+                    ln.weight.copy_(torch.linspace(0.5, 1.5, D))
+                    ln.bias.copy_(torch.linspace(-0.1, 0.1, D))
+            mod_a, mod_b = MoEBlock(norms[0], full).train(), MoEBlock(norms[1], epl).train()
+
+        def step(mod, layer, xin):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                out = mod(xin)
+                reg = sum(layer.get_reg_loss().values())
+            torch.autograd.backward([out, reg.float()], [dy.to(out.dtype), torch.ones((), device=dev)])
+            return out, reg
+        oa, ra = step(mod_a, full, xa)
+        ob, rb = step(mod_b, epl, xb)
+        torch.cuda.synchronize()
+        ok = torch.equal(oa, ob) and float(ra) == float(rb)
+        # fp32: every row goes through the same kernels -> the same bits.  bf16: d w is a sum of exact fp32 products whose grouping
+        # follows the dH launch's tile class, chosen from the row count of the launch (T*K rows there, the received rows here): the
+        # last fp32 bits of d w may differ, and with them a rounding of dx here and there
+        if autocast:
+            err = float((xa.grad - xb.grad).norm() / xa.grad.norm())
+            ok = ok and err <= 1e-5
+        else:
+            ok = ok and torch.equal(xa.grad, xb.grad)
+        tol = 1e-5 if not autocast else 3e-3
+        names = ["keys", "values"] + (["bias"] if bias else [])
+        for nme in names:
+            gr = getattr(full, nme).grad.detach().float().cpu()
+            if world > 1:
+                dist.all_reduce(gr)
+            gm = getattr(epl, nme).grad.detach().float().cpu()
+            gr = gr[rank * El:(rank + 1) * El]
+            ok = ok and float((gm - gr).norm() / (gr.norm() + 1e-12)) <= tol
+        for nme in ["w_gate"] + (["o_bias"] if bias else []):
+            gr = getattr(full, nme).grad.detach().float().cpu()
+            if world > 1:
+                dist.all_reduce(gr)
+            ok = ok and float((getattr(epl, nme).grad.float().cpu() - gr).norm() / gr.norm()) <= tol
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
 def _launch(world, backend, dt_name, chunks=1, empty_half=False, target=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -257,6 +372,22 @@ def test_ep_with_experts_that_receive_nothing(world, backend, chunks):
     """Half of the experts are never selected: empty groups of the overlapped exchange, zero-row grouped GEMMs, and (world 2) a
     rank that receives no rows at all and still takes part in every collective."""
     assert _launch(world, backend, "fp32", chunks, True) == {r: True for r in range(world)}
+
+
+@pytest.mark.parametrize("world,backend,dt_name,chunks,empty_half,direct",
+                         [(1, "nccl", "fp32", 1, False, False), (1, "nccl", "bf16", 1, False, False), (1, "nccl", "bf16", 3, False, True),
+                          (1, "nccl", "bf16_bias", 2, False, False), (2, "gloo", "fp32", 1, False, False), (2, "gloo", "bf16", 2, False, False),
+                          (2, "gloo", "bf16_bias", 2, False, True), (2, "gloo", "bf16", 2, True, False), (4, "gloo", "bf16", 2, False, True),
+                          (2, "gloo", "fp32", 1, True, True), (1, "nccl", "bf16_block", 2, False, False), (2, "gloo", "bf16_block", 2, False, True),
+                          (1, "nccl", "bf16_big", 2, False, False), (2, "gloo", "bf16_big", 1, False, True)])
+def test_pretrain_smoe_ep_equals_single_gpu(world, backend, dt_name, chunks, empty_half, direct, monkeypatch):
+    """Pretrain `smoe_ep` (packed experts sharded over the group, `ep.EPFFNPacked`): the single-GPU pretrain `smoe` layer's output and
+    regulariser bit for bit, dx bit for bit in fp32 and to 1e-5 under bf16 autocast (see the worker), local expert gradients equal to
+    the all-reduced single-GPU ones, replicated gate / o_bias gradients summed over the ranks -- plain and overlapped, per-peer and
+    direct exchange, with experts (and at world 2 a whole rank) that receive nothing, and inside the pretrain block (fp32 residual stream
+    added in the combine, logits from the fused LayerNorm + gate launch)."""
+    monkeypatch.setenv("CSMOE_EP_DIRECT", "1" if direct else "0")
+    assert _launch(world, backend, dt_name, chunks, empty_half, target=_run_pretrain) == {r: True for r in range(world)}
 
 
 def test_bench_script_runs_small_config_and_ep_path():
