@@ -52,10 +52,11 @@ def kernel_sources_hash():
 
 def workload_key(config, dtype):
     """What a traffic figure belongs to: the workload sentence of the JSON line (stack, routing, sizes, experts), the arithmetic
-    type and the parallelism.  tools/summarize_profile.py writes it from the bench line printed under rocprofv3; traffic_for
+    type, the parallelism and, for the expert-parallel layer (also when forced onto one rank), its exchange form.  tools/summarize_profile.py writes it from the bench line printed under rocprofv3; traffic_for
     reads it back for the run being timed."""
     return {"workload": config["workload"], "dtype": dtype, "parallelism": config["parallelism"],
-            "graph_replay": bool(config.get("graph_replay", False))}
+            "graph_replay": bool(config.get("graph_replay", False)),
+            "ep": [config["ep_chunks"], bool(config.get("ep_direct", False))] if "ep_chunks" in config else None}
 
 
 def traffic_for(kernel, config, dtype):

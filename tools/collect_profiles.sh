@@ -2,7 +2,7 @@
 # Copy the summaries tools/profile_all.sh left under gpurun_out/<workload>/ into profiles/<round>/ (tracked) and merge their
 # traffic.json entries.  usage (repo root, after the gpurun call): tools/collect_profiles.sh r03 [workload ...]
 R=$1; shift
-LIST=${*:-head pretrain fp8 fp8_cached siglip force_ep force_ep_direct competition8 competition}
+LIST=${*:-head pretrain fp8 fp8_cached siglip force_ep force_ep_direct pretrain_ep competition8 competition}
 mkdir -p profiles/$R
 for w in $LIST; do
   d=gpurun_out/$w

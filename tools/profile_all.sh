@@ -11,10 +11,11 @@ declare -A W=(
   [siglip]="--tokens 12800 --seq 2560 --d-model 1152 --d-ff 4304 --experts 4"
   [force_ep]="--force-ep"
   [force_ep_direct]="--force-ep --ep-direct"
+  [pretrain_ep]="--stack pretrain --force-ep"
   [competition8]="--competition --experts 8"
   [competition]="--competition"
 )
-LIST=${*:-head pretrain fp8 fp8_cached siglip force_ep force_ep_direct competition8 competition}
+LIST=${*:-head pretrain fp8 fp8_cached siglip force_ep force_ep_direct pretrain_ep competition8 competition}
 for w in $LIST; do
   echo "=== $w: bench.py ${W[$w]}  ($(date +%T))"
   st=20; [[ $w == competition* ]] && st=5
