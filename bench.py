@@ -107,7 +107,7 @@ def parse():
     ap.add_argument("--block", action="store_true", help="time the block around the layer, x + MoE(LayerNorm(x)) (SURVEY.md section 8 f1), with the fused LayerNorm+gate / residual-combine kernels")
     ap.add_argument("--block-unfused", action="store_true", help="same block composed from torch LayerNorm, the plain layer and a torch add (A/B for --block)")
     ap.add_argument("--stack", default="llava", choices=["llava", "pretrain"], help="pretrain: the LM-pretrain stack's `smoe` layer (packed fp32 master weights keys/values, ReLU, no bias, bf16 autocast: the cvmm path) instead of the LLaVA-stack layer")
-    ap.add_argument("--ep-chunks", type=int, default=0, help="expert-parallel runs: groups of local experts whose all-to-all overlaps the grouped GEMMs (competesmoe_amd.ep); 0 = pick the fastest of 1 / 2 / 4 in a short untimed trial before the warmup (1 with a single rank)")
+    ap.add_argument("--ep-chunks", type=int, default=0, help="expert-parallel runs: groups of local experts whose all-to-all overlaps the grouped GEMMs (competesmoe_amd.ep); 0 = pick the fastest of 1 / 2 / 4 / one expert per group in a short untimed trial before the warmup (1 with a single rank)")
     ap.add_argument("--ep-trial", action="store_true", help="run the overlap-depth trial even with a single rank (exercises the N>1 control flow on one GPU)")
     ap.add_argument("--stub", action="store_true", help="launcher test: CPU stand-in step over gloo, no GPU (tests/test_bench_launcher.py)")
     ap.add_argument("--ep-direct", action="store_true", help="expert-parallel runs: one message per (peer, local expert) delivered expert-major "
@@ -419,8 +419,9 @@ def main():
             layer.chunks = max(1, a.ep_chunks)
         else:   # untimed trial: overlap depth that is fastest on THIS node (max over ranks, so every rank picks the same)
             ep_tune = {}
-            for c in (1, 2, 4):
-                if c > a.experts // world:
+            El = a.experts // world
+            for c in sorted({1, 2, 4, El} if El <= 16 else {1, 2, 4}):     # El groups = one expert each: no regroup passes
+                if c > El:
                     continue
                 layer.chunks = c
                 step()

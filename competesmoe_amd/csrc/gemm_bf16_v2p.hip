@@ -451,8 +451,11 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
   static const int band = [] { const char* e = getenv("CSMOE_WGRAD_BAND"); return e ? atoi(e) : 4; }();
   p.tile_band = band;
   int64_t grid = (int64_t)E * ((Na + BM2 - 1) / BM2) * ((Nb + BN2 - 1) / BN2);
-  // the dealt order needs the persistent grid to be a multiple of 8 (workgroup id % 8 = XCD)
-  p.xcd_order = (offsets && xcd_order && persistent_grid(grid) % 8 == 0 && persistent_grid(grid) < grid) ? xcd_order : nullptr;
+  // the dealt order needs the persistent grid to be a multiple of 8 (workgroup id % 8 = XCD) and enough experts to deal: every XCD
+  // gets WHOLE experts, so 4 experts (one group of an expert-parallel rank's 8, ep.py) kept 4 of the 8 XCDs idle -- 2 x the time
+  // per launch -- and 12 would give four XCDs twice the others' work.  Otherwise: one contiguous chunk of the tile order per XCD.
+  const bool deal = offsets && xcd_order && (E % 8 == 0 || E >= 64);
+  p.xcd_order = (deal && persistent_grid(grid) % 8 == 0 && persistent_grid(grid) < grid) ? xcd_order : nullptr;
   if (grid <= 0) return CSMOE_OK;
   if (grid > 0x7fffffff) { csmoe_set_error("grouped_wgrad: grid too large"); return CSMOE_ERR_UNSUPPORTED; }
   int rc;

@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .functional import ExpertTable
+from .functional import ExpertTable, _grouped_colsum
 from .moe.moe import MoeLayer
 from .moe.register import register_moe
 
@@ -311,14 +311,10 @@ class EPFFN(torch.autograd.Function):
             ops.grouped_wgrad(dh, rs, lb.offsets, E, gW1, table(gW1), xcd_order=lb.xcd_order)
             seq = [gW1]
             if tab.b1_ptrs is not None:
-                gb1 = torch.empty(E, tab.F, dtype=pd, device=dev)
-                ops.grouped_colsum(dh, lb.offsets, E, gb1, table(gb1))
-                seq.append(gb1)
+                seq.append(_grouped_colsum(dh, lb.offsets, E, pd))      # rows cut into chunks when E * ceil(N / 512) would not fill the chip
             seq.append(gW2)
             if tab.b2_ptrs is not None:
-                gb2 = torch.empty(E, tab.Dout, dtype=pd, device=dev)
-                ops.grouped_colsum(dys, lb.offsets, E, gb2, table(gb2))
-                seq.append(gb2)
+                seq.append(_grouped_colsum(dys, lb.offsets, E, pd))
             pg = [g[e] for g in seq for e in range(E)]
         dx2 = None
         if ctx.needs_input_grad[0]:
@@ -358,7 +354,7 @@ class EPFFNChunked(torch.autograd.Function):
             with ops._timed("ep_wait_exposed"):
                 wk.wait()
             Ec = cp.e1 - cp.e0
-            if direct:
+            if direct or Ec == 1:       # one expert per group: rows grouped by source rank ARE expert-major, no regroup either way
                 lb, rs = local_bins(plan, cp.e0, cp.e1), r
             else:
                 lb = ops.bin_tokens(local_expert_ids(plan, cp.e0, cp.e1).view(-1, 1), Ec)
@@ -373,7 +369,7 @@ class EPFFNChunked(torch.autograd.Function):
                 ret = ys
                 back.append(exchange_direct(direct_views(y, plan, cp.e0, cp.e1, False), direct_views(ret, plan, cp.e0, cp.e1, True), group))
             else:
-                ret = ops.dispatch_rows(ys, _Unsort(lb))
+                ret = ys if Ec == 1 else ops.dispatch_rows(ys, _Unsort(lb))
                 back.append(exchange_views(_views(y, cp.send_lo, cp.send_n), _packed_views(ret, cp.recv_n), group))
             keep.append(ret)                             # alive until the return trip has been waited for
             saved.append((lb, rs, hpre, hact))
@@ -422,10 +418,8 @@ class EPFFNChunked(torch.autograd.Function):
             tW2, tW1 = table(gW2), table(gW1)
             if tab.b1_ptrs is not None:
                 gb1 = torch.empty(E, tab.F, dtype=pd, device=dev)
-                tb1 = table(gb1)
             if tab.b2_ptrs is not None:
                 gb2 = torch.empty(E, tab.Dout, dtype=pd, device=dev)
-                tb2 = table(gb2)
         dxs = torch.empty(bins.n, tab.D, dtype=dy.dtype, device=dev) if need_dx else None
         back, keep = [], []
         for cp, r, wk, (lb, rs, hpre, hact) in zip(cps, recvs, works, saved):
@@ -433,7 +427,7 @@ class EPFFNChunked(torch.autograd.Function):
                 wk.wait()
             e0, e1 = cp.e0, cp.e1
             Ec = e1 - e0
-            dys = r if direct else ops.dispatch_rows(r, lb)
+            dys = r if (direct or Ec == 1) else ops.dispatch_rows(r, lb)
             dh = ops.grouped_gemm(dys, tab.w2_ptrs[e0:e1], L.B_KN, tab.F, tab.F, lb.offsets, Ec, epilogue=L.EPI_ACTGRAD, act=tab.act,
                                   aux=hpre if hpre is not None else hact)
             if need_dx:                                  # input gradient first: its return trip overlaps this group's weight gradients
@@ -442,16 +436,16 @@ class EPFFNChunked(torch.autograd.Function):
                     ret = dxs_s
                     back.append(exchange_direct(direct_views(dxs, plan, e0, e1, False), direct_views(ret, plan, e0, e1, True), group))
                 else:
-                    ret = ops.dispatch_rows(dxs_s, _Unsort(lb))
+                    ret = dxs_s if Ec == 1 else ops.dispatch_rows(dxs_s, _Unsort(lb))
                     back.append(exchange_views(_views(dxs, cp.send_lo, cp.send_n), _packed_views(ret, cp.recv_n), group))
                 keep.append(ret)
             if need_params:
                 ops.grouped_wgrad(dys, hact, lb.offsets, Ec, gW2, tW2[e0:e1], xcd_order=lb.xcd_order)
                 ops.grouped_wgrad(dh, rs, lb.offsets, Ec, gW1, tW1[e0:e1], xcd_order=lb.xcd_order)
-                if gb1 is not None:
-                    ops.grouped_colsum(dh, lb.offsets, Ec, gb1, tb1[e0:e1])
+                if gb1 is not None:         # a group's few experts: _grouped_colsum cuts their rows into chunks to fill the chip
+                    gb1[e0:e1] = _grouped_colsum(dh, lb.offsets, Ec, pd)
                 if gb2 is not None:
-                    ops.grouped_colsum(dys, lb.offsets, Ec, gb2, tb2[e0:e1])
+                    gb2[e0:e1] = _grouped_colsum(dys, lb.offsets, Ec, pd)
         pg = [None] * ctx.n_params
         if need_params:
             seq = [gW1] + ([gb1] if gb1 is not None else []) + [gW2] + ([gb2] if gb2 is not None else [])
@@ -474,13 +468,14 @@ class _Lane:
 
     def __init__(self, plan: EPPlan, cp: EPChunk, direct: bool, group):
         self.plan, self.cp, self.direct, self.group = plan, cp, direct, group
+        self.as_is = direct or cp.e1 - cp.e0 == 1      # received rows are expert-major as they land (one expert: trivially)
         self._lb = None
 
     @property
     def lb(self) -> "ops.Bins":
         if self._lb is None:
             cp = self.cp
-            self._lb = (local_bins(self.plan, cp.e0, cp.e1) if self.direct else
+            self._lb = (local_bins(self.plan, cp.e0, cp.e1) if self.as_is else
                         ops.bin_tokens(local_expert_ids(self.plan, cp.e0, cp.e1).view(-1, 1), cp.e1 - cp.e0))
         return self._lb
 
@@ -496,7 +491,7 @@ class _Lane:
 
     def arrived(self, r: torch.Tensor) -> torch.Tensor:
         """A waited-for receive buffer as expert-major rows."""
-        if self.direct or r.shape[0] == 0:
+        if self.as_is or r.shape[0] == 0:
             return r
         return r[self.lb.perm.long()] if r.shape[1] == 1 else ops.dispatch_rows(r, self.lb)
 
@@ -506,7 +501,7 @@ class _Lane:
         if self.direct:
             return exchange_direct(direct_views(dst, self.plan, cp.e0, cp.e1, False), direct_views(rows, self.plan, cp.e0, cp.e1, True),
                                    self.group), rows
-        if rows.shape[0]:
+        if rows.shape[0] and not self.as_is:
             rows = rows[self.lb.slot_of.long()] if rows.shape[1] == 1 else ops.dispatch_rows(rows, _Unsort(self.lb))
         return exchange_views(_views(dst, cp.send_lo, cp.send_n), _packed_views(rows, cp.recv_n), self.group), rows
 
@@ -648,7 +643,6 @@ class EPFFNPacked(torch.autograd.Function):
             tk, tv = ops.ptr_table(gk, El, D * F * es), ops.ptr_table(gv, El, F * Dout * es)
             if tab.b1_ptrs is not None:
                 gb = torch.empty(El, F, dtype=pd, device=dev)
-                tb = ops.ptr_table(gb, El, F * es)
         dxs = torch.empty(bins.n, D, dtype=op, device=dev) if need_dx else None
         dots = torch.empty(bins.n, 1, dtype=torch.float32, device=dev) if use_dot else None
         back = []
@@ -684,7 +678,7 @@ class EPFFNPacked(torch.autograd.Function):
                 ops.grouped_wgrad(hact, dys, lb.offsets, Ec, gv, tv[e0:e1], xcd_order=lb.xcd_order)
                 ops.grouped_wgrad(rs, dh, lb.offsets, Ec, gk, tk[e0:e1], xcd_order=lb.xcd_order)
                 if gb is not None:
-                    ops.grouped_colsum(dh, lb.offsets, Ec, gb, tb[e0:e1])
+                    gb[e0:e1] = _grouped_colsum(dh, lb.offsets, Ec, pd)
         with ops._timed("ep_wait_exposed"):
             for wk, _ in back:
                 wk.wait()

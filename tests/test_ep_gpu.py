@@ -379,12 +379,13 @@ def test_ep_with_experts_that_receive_nothing(world, backend, chunks):
                           (1, "nccl", "bf16_bias", 2, False, False), (2, "gloo", "fp32", 1, False, False), (2, "gloo", "bf16", 2, False, False),
                           (2, "gloo", "bf16_bias", 2, False, True), (2, "gloo", "bf16", 2, True, False), (4, "gloo", "bf16", 2, False, True),
                           (2, "gloo", "fp32", 1, True, True), (1, "nccl", "bf16_block", 2, False, False), (2, "gloo", "bf16_block", 2, False, True),
-                          (1, "nccl", "bf16_big", 2, False, False), (2, "gloo", "bf16_big", 1, False, True)])
+                          (1, "nccl", "bf16_big", 2, False, False), (2, "gloo", "bf16_big", 1, False, True), (2, "gloo", "bf16", 4, False, False)])
 def test_pretrain_smoe_ep_equals_single_gpu(world, backend, dt_name, chunks, empty_half, direct, monkeypatch):
     """Pretrain `smoe_ep` (packed experts sharded over the group, `ep.EPFFNPacked`): the single-GPU pretrain `smoe` layer's output and
     regulariser bit for bit, dx bit for bit in fp32 and to 1e-5 under bf16 autocast (see the worker), local expert gradients equal to
     the all-reduced single-GPU ones, replicated gate / o_bias gradients summed over the ranks -- plain and overlapped, per-peer and
-    direct exchange, with experts (and at world 2 a whole rank) that receive nothing, and inside the pretrain block (fp32 residual stream
+    direct exchange, one expert per group (no regroup passes on the per-peer road), with experts (and at world 2 a whole rank) that
+    receive nothing, and inside the pretrain block (fp32 residual stream
     added in the combine, logits from the fused LayerNorm + gate launch)."""
     monkeypatch.setenv("CSMOE_EP_DIRECT", "1" if direct else "0")
     assert _launch(world, backend, dt_name, chunks, empty_half, target=_run_pretrain) == {r: True for r in range(world)}
@@ -409,8 +410,8 @@ def test_bench_script_runs_small_config_and_ep_path():
                   "dtype", "data", "config", "roofline"):
             assert k in d, k
         assert d["value"] > 0 and d["n_gpus"] == 1 and d["config"]["workload"]
-        if "--ep-trial" in extra:          # the N>1 control flow: trial of 1 / 2 / 4 groups, then the chosen depth
-            assert set(d["config"]["ep_chunks_trial_ms"]) == {"1", "2", "4"} and d["config"]["ep_chunks"] in (1, 2, 4)
+        if "--ep-trial" in extra:          # the N>1 control flow: trial of 1 / 2 / 4 groups and one expert per group (8), then the choice
+            assert set(d["config"]["ep_chunks_trial_ms"]) == {"1", "2", "4", "8"} and d["config"]["ep_chunks"] in (1, 2, 4, 8)
         elif extra:
             assert ("ep_wait_exposed" if "--ep-chunks" in extra else "ep_all_to_all") in d["kernels"]
             assert d["config"]["ep_chunks"] == (2 if "--ep-chunks" in extra else 1)
