@@ -580,7 +580,10 @@ class EPFFNPacked(torch.autograd.Function):
             e0, e1 = ln.cp.e0, ln.cp.e1
             rs, lb = ln.arrived(r), ln.lb
             b1c = None if b1 is None else b1[e0:e1]
-            if in_fill and ops.f32w_ok(rs.shape[0], F, D) and ops.f32w_ok(rs.shape[0], Dout, F):
+            # the converting launch covers ONE row tile per expert (ceil(N / 256) workgroups each): with fewer than 4 experts it leaves
+            # most of the chip idle while it streams their fp32 weights (tools/ep_groups_ab.sh 8 --stack pretrain: 0.80 against 0.62 ms
+            # per single-expert GEMM) -- such groups cast their slice and take the plain kernels
+            if in_fill and e1 - e0 >= 4 and ops.f32w_ok(rs.shape[0], F, D) and ops.f32w_ok(rs.shape[0], Dout, F):
                 hpre, hact = ops.grouped_gemm_f32w(rs, keys[e0:e1], lb.offsets, copy=k_op[e0:e1], bias_ptrs=b1c, epilogue=epi1, act=act,
                                                    want_c2=True, want_c=act != L.ACT_RELU)
                 ys = ops.grouped_gemm_f32w(hact, values[e0:e1], lb.offsets, copy=v_op[e0:e1])

@@ -11,6 +11,9 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 CMD="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA"
 python3 bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline $EXTRA > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || exit 1
+# ONLY_BENCH=1: just the bench line again (after traffic.json of THIS build has been collected into profiles/rNN/, so that the committed
+# line carries roofline.traffic instead of "collected on other kernel sources")
+[ -n "${ONLY_BENCH:-}" ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o t -- $CMD > $OUT/bench_${TAG}_under_rocprof.json 2> $OUT/kt.err || exit 1
 timeout -k 10 ${PROF_TIMEOUT:-400} rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pf -o t -- $CMD > /dev/null 2> $OUT/pf.err || exit 1
