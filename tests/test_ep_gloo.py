@@ -238,3 +238,53 @@ def test_competition_exchanges_two_ranks_gloo():
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+def _pretrain_ctor_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        import torch.nn.functional as F
+        from competesmoe_amd.pretrain import get_moe
+        args = types.SimpleNamespace(balance_loss_coef=0.01)
+        lay = get_moe("smoe_ep")(32, 8, 16, n_heads=2, activation=F.relu, bias=True, args=args)
+        ok = tuple(lay.w_gate.shape) == (8, 32) and tuple(lay.keys.shape) == (8 // world, 32, 16)
+        ok = ok and tuple(lay.values.shape) == (8 // world, 16, 32) and tuple(lay.bias.shape) == (8 // world, 16)
+        ok = ok and set(lay.state_dict()) == {"w_gate", "keys", "values", "bias", "o_bias"} and lay.n_experts == 8
+        try:
+            get_moe("smoe_ep")(32, 9, 16, n_heads=2, activation=F.relu, args=args)       # 9 experts do not divide over the ranks
+            ok = ok and world == 1
+        except ValueError:
+            pass
+        # the replicated gate's gradient is summed over the group once per backward pass
+        (lay.w_gate * (rank + 1.0)).sum().backward()
+        ok = ok and torch.equal(lay.w_gate.grad, torch.full_like(lay.w_gate, float(sum(r + 1 for r in range(world)))))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pretrain_smoe_ep_holds_its_share_of_the_packed_experts_gloo():
+    """Pretrain `smoe_ep` (pretrain/smoe_ep.py) at world 2 on the CPU: the constructor takes the arguments of `smoe`, holds E/P experts
+    of the packed tensors under the reference's parameter names, refuses an expert count the ranks do not divide, and sums the
+    replicated gate's gradient over the group.  (Its forward / backward against the single-GPU layer: tests/test_ep_gpu.py.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pretrain_ctor_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
+def test_pretrain_smoe_ep_needs_a_process_group():
+    import types
+    import torch.nn.functional as F
+    from competesmoe_amd.pretrain import get_moe
+    with pytest.raises(RuntimeError, match="process group"):
+        get_moe("smoe_ep")(32, 8, 16, n_heads=2, activation=F.relu, args=types.SimpleNamespace(balance_loss_coef=0.01))
