@@ -178,6 +178,10 @@ __device__ __forceinline__ int grouped_total_tiles(const int32_t* offsets, int E
   }
   return total;
 }
+// WHOLE > 0: an expert with at most WHOLE row tiles is ONE band (column tiles in order, all its row tiles under each) -- the
+// one-wave-per-SIMD kernel's NT launches run 1.3 % faster that way at the headline's 4-5 row tiles per expert (tools/band_ab.sh: 5.06
+// -> 4.99 ms with bands of 5, 6 or 8), the 8-wave kernel's NN launches 0.6 % slower, and tall experts want bands of 4 on both.
+template <int WHOLE = 0>
 __device__ __forceinline__ bool grouped_find_tile(const int32_t* offsets, int E, int single_M, int BMt, int nct, int v, int lane,
                                                   TilePos& out, int part = 0) {
   int acc = 0;
@@ -200,9 +204,10 @@ __device__ __forceinline__ bool grouped_find_tile(const int32_t* offsets, int E,
       // a time are then a 4 x 8 block sharing 4 row panels and 8 weight panels.  With at most TILE_BAND row tiles per expert (the
       // headline: ~4) this IS the plain (n-tile, m-tile) order; with many (a dense always-on expert: 128 row tiles) the plain order
       // made 32 concurrent tiles share ONE weight panel and stream 32 row panels.
-      const int band = local / (TILE_BAND * nct), rem = local - band * TILE_BAND * nct;
-      const int g_eff = min(TILE_BAND, mte - band * TILE_BAND);
-      out.mt = band * TILE_BAND + rem % g_eff + (part == 2 ? 1 : 0);
+      const int bh = (WHOLE > 0 && mte <= WHOLE) ? max(mte, 1) : TILE_BAND;          // band height
+      const int band = local / (bh * nct), rem = local - band * bh * nct;
+      const int g_eff = min(bh, mte - band * bh);
+      out.mt = band * bh + rem % g_eff + (part == 2 ? 1 : 0);
       out.nt = rem / g_eff;
       return true;
     }

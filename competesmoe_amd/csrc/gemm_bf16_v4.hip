@@ -111,6 +111,9 @@ __device__ __forceinline__ void dma_piece4(LoopState& st, int tile) {
 }
 
 // slot table parameters (tools/v4_tune.sh builds twins with other values)
+#ifndef CSMOE_V4_WHOLE
+#define CSMOE_V4_WHOLE 8      // tile order: experts of at most this many row tiles are one band (common.h grouped_find_tile); 0 = bands of 4 always
+#endif
 #ifndef CSMOE_V4_RSTEP
 #define CSMOE_V4_RSTEP 2      // early reads: one every RSTEP slots from slot 0
 #define CSMOE_V4_BAR 34       // slot of the "K-tile in registers" barrier
@@ -210,7 +213,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int total = grouped_total_tiles(p.offsets, p.E, p.single_M, BM4, nct, lane);
     if ((int)blockIdx.x >= total) return;
     const int v = xcd_remap(blockIdx.x, total);
-    if (!grouped_find_tile(p.offsets, p.E, p.single_M, BM4, nct, v, lane, tp)) return;
+    if (!grouped_find_tile<CSMOE_V4_WHOLE>(p.offsets, p.E, p.single_M, BM4, nct, v, lane, tp)) return;
   }
   const int e = __builtin_amdgcn_readfirstlane(tp.e);
   const int row0 = __builtin_amdgcn_readfirstlane(tp.o0 + tp.mt * BM4);
