@@ -726,7 +726,8 @@ class EPSMoeLayer(MoeLayer):
         self.group = group
         self.chunks = chunks        # groups of local experts whose exchanges overlap the GEMMs; None: CSMOE_EP_CHUNKS, else 2 (1 at P=1)
         # one message per (peer, local expert) instead of one per peer + regroup passes (exchange_direct); None: CSMOE_EP_DIRECT, else
-        # off -- the per-peer exchange is the form that has run on more than one rank of real hardware least untested
+        # off -- the per-peer all-to-all is the pattern collective libraries are tuned for; this one has not run between two GPUs yet
+        # 
         self.direct = direct
         self.init_gate_weights()
         reduce_grad_on_backward(self.gate.weight, group)
