@@ -50,6 +50,17 @@ constexpr int LDS2_BYTES = STG_OFF + 64 * CT2_LD * 4; // 132,096 B  (>= 8 * TILE
 #define STAMP(k) do { } while (0)
 #endif
 
+// Gradient tiles are written once and read by the optimizer much later: non-temporal stores keep them from displacing the operand
+// panels in L2.  CSMOE_WG_NT=0: plain stores (A/B).
+#ifndef CSMOE_WG_NT
+#define CSMOE_WG_NT 1
+#endif
+#if CSMOE_WG_NT
+#define WG_STORE(ptr, val) __builtin_nontemporal_store(val, ptr)
+#else
+#define WG_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 struct TileW { int e, row0, red_len, tr0, tc0; };     // wave-uniform
 struct DmaW {
   __amdgpu_buffer_rsrc_t rs_r, rs_c;
@@ -314,7 +325,7 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
               const int trow = h * 128 + er + 16 * (jj + j);
               if (trow < nrows) {
                 typedef __attribute__((address_space(1))) bf16x8 gbf16x8;
-                *(gbf16x8*)(Ce + ((int64_t)(cur.tr0 + trow) * p.ldc + ncol) * 2) = row[j];
+                WG_STORE((gbf16x8*)(Ce + ((int64_t)(cur.tr0 + trow) * p.ldc + ncol) * 2), row[j]);
               }
             }
           }
@@ -358,7 +369,7 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
 #if CSMOE_WG_VARIANT == 2                 // timing experiment: no global stores at all (results are wrong): what the stores cost
               if (a[0] == 1.2345e30f) dst[0] = a;
 #else
-              dst[0] = a;
+              WG_STORE(dst, a);
 #endif
             }
           }
@@ -388,7 +399,7 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
               gf32x4* dst = (gf32x4*)(Ce + o * 4);
               f32x4 a = lo[j], b = hi[j];
               if (p.accumulate) { a += dst[0]; b += dst[1]; }
-              dst[0] = a; dst[1] = b;
+              WG_STORE(dst, a); WG_STORE(dst + 1, b);
             } else {
               typedef __attribute__((address_space(1))) bf16x8 gbf16x8;
               gbf16x8* dst = (gbf16x8*)(Ce + o * 2);
@@ -401,7 +412,7 @@ __global__ void __launch_bounds__(512, 2) gg8w_kernel(FastArgs p) {
               bf16x8 o8;
 #pragma unroll
               for (int t = 0; t < 8; ++t) o8[t] = (bf16)vv[t];
-              *dst = o8;
+              WG_STORE(dst, o8);
             }
           }
         }
