@@ -459,8 +459,12 @@ int gg8_wgrad(const void* A, int64_t lda, const void* B, int64_t ldb, const int3
   p.single_M = single_M; p.single_C = single_C;
   p.R = A; p.ld_r = lda; p.Cflat = B; p.ld_c = ldb; p.offsets = offsets; p.E = E; p.NR = Na; p.NC = Nb;
   p.out_ptrs = c_ptrs; p.ldc = ldc; p.accumulate = accumulate; p.out_f32 = (out_dtype == CSMOE_F32);
-  static const int band = [] { const char* e = getenv("CSMOE_WGRAD_BAND"); return e ? atoi(e) : 4; }();
-  p.tile_band = band;
+  // band height of the tile order (tile_of): 5 for the experts of a grouped launch, 4 for one dense matrix.  Swept again with the
+  // non-temporal stores in place (bands of 2 / 3 / 4 / 5 / 6 / 8, sum of the headline's two launches: 10.40 / 10.23 / 10.33 / 10.20 /
+  // 10.19 / 10.48 ms; fp32 gradients 4 / 5 / 6: 12.15 / 11.80 / 11.84 ms at 64 experts, 15.35 / 14.72 / 15.1 at 128 x 512 rows; the
+  // dense launches of the competition pass 2.148 / 2.178 / 2.166 ms).  CSMOE_WGRAD_BAND=<n> forces one height for both (A/B).
+  static const int band_env = [] { const char* e = getenv("CSMOE_WGRAD_BAND"); return e ? atoi(e) : 0; }();
+  p.tile_band = band_env > 0 ? band_env : (offsets ? 5 : 4);
   int64_t grid = (int64_t)E * ((Na + BM2 - 1) / BM2) * ((Nb + BN2 - 1) / BN2);
   // the dealt order needs the persistent grid to be a multiple of 8 (workgroup id % 8 = XCD) and enough experts to deal: every XCD
   // gets WHOLE experts, so 4 experts (one group of an expert-parallel rank's 8, ep.py) kept 4 of the 8 XCDs idle -- 2 x the time
