@@ -77,6 +77,8 @@ SIGNATURES = {
     "csmoe_layernorm_bwd_mixed": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "csmoe_combine_mixed": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "csmoe_combine_bwd_mixed": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "csmoe_dispatch_rows_bwd_mixed": (_i, [_p, _p, _i, _p, _p, _i, _i, _p]),
+    "csmoe_widen_sum": (_i, [_p, _p, _p, _p, _l, _p]),
     "csmoe_grouped_gemm_f32w": (_i, [_p, _l, _p, _l, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _l, _i, _i, _p]),
     "csmoe_quantize_mxfp8": (_i, [_p, _p, _i, _l, _i, _i, _i, _i, _p, _p, _p]),
     "csmoe_quantize_mxfp8_both": (_i, [_p, _p, _i, _l, _i, _i, _i, _p, _p, _p, _p, _p]),

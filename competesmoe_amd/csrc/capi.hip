@@ -71,6 +71,8 @@ int k_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* idx, c
                     int D, int mode, hipStream_t st);
 int k_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of, const float* w, void* dy, float* dw, int T, int K,
                         int D, hipStream_t st);
+int k_dispatch_rows_bwd_mixed(const void* dxs, const int32_t* slot_of, int K, const void* add, float* dx, int T, int D, hipStream_t st);
+int k_widen_sum(const void* a, const void* b, const void* c, float* out, int64_t n, hipStream_t st);
 int k_layernorm_fwd_mixed(const float* x, const float* gamma, const float* beta, float eps, void* xn, float* mean, float* rstd, int T,
                           int D, hipStream_t st);
 int k_layernorm_bwd_mixed(const void* dxn, const void* dxn2, const float* x, const float* gamma, const float* mean, const float* rstd,
@@ -552,6 +554,22 @@ int csmoe_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slo
   CSMOE_CHECK_ARG(T == 0 || (dout && slot_of && dy), "combine_bwd_mixed: null pointer");
   CSMOE_CHECK_ARG((((uintptr_t)y | (uintptr_t)dout | (uintptr_t)dy) & 15) == 0, "combine_bwd_mixed: operands must be 16-byte aligned");
   return k_combine_bwd_mixed(dout, y, slot_of, w, dy, dw, T, K, D, (hipStream_t)stream);
+}
+
+int csmoe_dispatch_rows_bwd_mixed(const void* dxs, const int32_t* slot_of, int K, const void* add, float* dx, int T, int D,
+                                  csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(K > 0 && K <= 64 && T >= 0 && D > 0 && D % 8 == 0, "dispatch_rows_bwd_mixed: bad arguments (K <= 64, D a multiple of 8)");
+  CSMOE_CHECK_ARG(T == 0 || (dxs && slot_of && dx), "dispatch_rows_bwd_mixed: null pointer");
+  CSMOE_CHECK_ARG((((uintptr_t)dxs | (uintptr_t)add | (uintptr_t)dx) & 15) == 0, "dispatch_rows_bwd_mixed: operands must be 16-byte aligned");
+  return k_dispatch_rows_bwd_mixed(dxs, slot_of, K, add, dx, T, D, (hipStream_t)stream);
+}
+
+int csmoe_widen_sum(const void* a, const void* b, const void* c, float* out, int64_t n, csmoe_stream_t stream) {
+  CSMOE_CHECK_ARG(n >= 0, "widen_sum: bad length");
+  CSMOE_CHECK_ARG(n == 0 || (a && out), "widen_sum: null pointer");
+  CSMOE_CHECK_ARG(!c || b, "widen_sum: streams are given in order (c without b)");
+  CSMOE_CHECK_ARG((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0, "widen_sum: operands must be 16-byte aligned");
+  return k_widen_sum(a, b, c, out, n, (hipStream_t)stream);
 }
 
 

@@ -321,9 +321,11 @@ __global__ void __launch_bounds__(256) dispatch_tokens_reg_kernel(const char* x,
 constexpr int COMBINE_SEQ_DESC = 3;   // internal: CSMOE_COMBINE_SEQ with the slots visited in descending expert order (dispatch backward)
 // TO = type of the residual `add` and of `out`: T, or float with T = bf16 (the pretrain stack's fp32 residual stream under
 // bf16 autocast: the combine result is rounded to bf16 like the reference's cvmm output, then added to the fp32 residual in fp32)
-template <typename T, int VEC, typename TO = T>
+// TA = type of `add` alone when it differs from the output's: bf16 with TO = float is the dispatch backward of that stack, where the
+// gate's bf16 gradient of x meets the experts' in the fp32 stream (csmoe_dispatch_rows_bwd_mixed)
+template <typename T, int VEC, typename TO = T, typename TA = TO>
 __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t* slot_of, const int32_t* idx, const float* w,
-                                                      const T* obias, const TO* add, TO* out, int Tn, int K, int D, int mode,
+                                                      const T* obias, const TA* add, TO* out, int Tn, int K, int D, int mode,
                                                       const T* pre) {
 #pragma clang fp contract(off)   // the sequential rule is "multiply, round, add, round": no FMA contraction
   constexpr bool O32 = !std::is_same<T, TO>::value;
@@ -373,8 +375,8 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
 #pragma unroll
       for (int v = 0; v < VEC; ++v) addv[v] = 0.f;
       if (add && live) {
-        const TO* arow = add + (int64_t)t * D + d0;
-        if constexpr (O32) {
+        const TA* arow = add + (int64_t)t * D + d0;
+        if constexpr (O32 && std::is_same<TA, float>::value) {
           const f32x4 ra = *(const f32x4*)arow, rb = *(const f32x4*)(arow + 4);
 #pragma unroll
           for (int v = 0; v < 4; ++v) { addv[v] = ra[v]; addv[4 + v] = rb[v]; }
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
 #pragma unroll
           for (int v = 0; v < VEC; ++v) addv[v] = r4[v];
         } else {
-          addv[0] = DT<TO>::ld(arow);
+          addv[0] = DT<TA>::ld(arow);
         }
       }
       for (int kk = 0; kk < K; ++kk) {
@@ -454,9 +456,9 @@ __global__ void __launch_bounds__(256) combine_kernel(const T* y, const int32_t*
 // K == 2, bf16 rows, D a multiple of 512 (the headline case): the same arithmetic with eight row loads (+ four residual loads) in
 // flight per lane -- four 8-column chunks of both selected rows are fetched before the first add.  The generic kernel above has one
 // dependent load per (chunk, k) in flight and stays at 4.6-5.0 TB/s.
-template <typename TO>
+template <typename TO, typename TA = TO>
 __global__ void __launch_bounds__(256) combine_k2_kernel(const bf16* y, const int32_t* slot_of, const int32_t* idx, const float* w,
-                                                         const bf16* obias, const TO* add, TO* out, int Tn, int D, int mode) {
+                                                         const bf16* obias, const TA* add, TO* out, int Tn, int D, int mode) {
 #pragma clang fp contract(off)
   constexpr bool O32 = std::is_same<TO, float>::value;
   const int lane = threadIdx.x & 63;
@@ -482,8 +484,8 @@ __global__ void __launch_bounds__(256) combine_k2_kernel(const bf16* y, const in
           a[c] = *(const bf16x8*)(r0 + d0);
           b[c] = *(const bf16x8*)(r1 + d0);
           if (add) {
-            const TO* arow = add + (int64_t)t * D + d0;
-            if constexpr (O32) {
+            const TA* arow = add + (int64_t)t * D + d0;
+            if constexpr (std::is_same<TA, float>::value) {
               const f32x4 ra = *(const f32x4*)arow, rb = *(const f32x4*)(arow + 4);
 #pragma unroll
               for (int v = 0; v < 4; ++v) { addv[c][v] = ra[v]; addv[c][4 + v] = rb[v]; }
@@ -1355,6 +1357,22 @@ int k_combine(const void* y, const int32_t* slot_of, const int32_t* idx, const f
   return CSMOE_OK;
 }
 
+// dispatch backward into an fp32 stream: bf16 rows, bf16 `add`, fp32 output; D % 8 == 0 and 16-byte alignment checked by the caller
+int k_dispatch_rows_bwd_mixed(const void* dxs, const int32_t* slot_of, int K, const void* add, float* dx, int T, int D, hipStream_t st) {
+  if (T == 0) return CSMOE_OK;
+  static const bool generic_only = getenv("CSMOE_COMBINE_GENERIC") != nullptr;
+  if (K == 2 && D % 512 == 0 && !generic_only)
+    hipLaunchKernelGGL((combine_k2_kernel<float, bf16>), dim3(stride_grid(T)), dim3(256), 0, st, (const bf16*)dxs, slot_of,
+                       (const int32_t*)nullptr, (const float*)nullptr, (const bf16*)nullptr, (const bf16*)add, dx, T, D,
+                       (int)CSMOE_COMBINE_DOT);
+  else
+    hipLaunchKernelGGL((combine_kernel<bf16, 8, float, bf16>), dim3(stride_grid(T)), dim3(256), 0, st, (const bf16*)dxs, slot_of,
+                       (const int32_t*)nullptr, (const float*)nullptr, (const bf16*)nullptr, (const bf16*)add, dx, T, K, D,
+                       (int)CSMOE_COMBINE_DOT, (const bf16*)nullptr);
+  CSMOE_CHECK_LAUNCH("dispatch_rows_bwd_mixed");
+  return CSMOE_OK;
+}
+
 int k_combine_bwd(const void* dout, const void* y, const int32_t* perm, const float* w, void* dy, float* dw, int n, int K, int D,
                   int dtype, int round_prod, hipStream_t st) {
   // `perm` here is slot_of (token-major traversal); n = T
@@ -1410,6 +1428,58 @@ int k_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of
     hipLaunchKernelGGL((combine_bwd_kernel<bf16, 8, float>), dim3(stride_grid(T)), dim3(256), 0, st, dout, (const bf16*)y, slot_of, w,
                        (bf16*)dy, dw, T, K, D, 0);
   CSMOE_CHECK_LAUNCH("combine_bwd_mixed");
+  return CSMOE_OK;
+}
+
+// out[i] = (float(a[i]) + float(b[i])) + float(c[i])  (b, c may be null): bf16 gradient streams of an fp32 tensor, each widened by
+// its cast's backward and added by the autograd engine in fp32 (csmoe_widen_sum) -- one pass instead of a cast per stream and an
+// fp32 add per pair.  Four 16-byte chunks per stream in flight per lane; the tail (n % 8 elements) is scalar.
+__global__ void __launch_bounds__(256) widen_sum_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const bf16* __restrict__ c,
+                                                        float* __restrict__ out, int64_t n) {
+#pragma clang fp contract(off)
+  const int64_t n8 = n >> 3, step = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n8; i0 += 4 * step) {
+    bf16x8 va[4], vb[4], vc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * step;
+      if (i < n8) {
+        va[u] = ((const bf16x8*)a)[i];
+        if (b) vb[u] = ((const bf16x8*)b)[i];
+        if (c) vc[u] = ((const bf16x8*)c)[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * step;
+      if (i >= n8) continue;
+      float r[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        r[v] = (float)va[u][v];
+        if (b) r[v] = r[v] + (float)vb[u][v];
+        if (c) r[v] = r[v] + (float)vc[u][v];
+      }
+      float* o = out + i * 8;
+      *(f32x4*)o = f32x4{r[0], r[1], r[2], r[3]};
+      *(f32x4*)(o + 4) = f32x4{r[4], r[5], r[6], r[7]};
+    }
+  }
+  if (blockIdx.x == 0 && (n8 << 3) + threadIdx.x < n) {
+    const int64_t i = (n8 << 3) + threadIdx.x;
+    float r = (float)a[i];
+    if (b) r = r + (float)b[i];
+    if (c) r = r + (float)c[i];
+    out[i] = r;
+  }
+}
+
+int k_widen_sum(const void* a, const void* b, const void* c, float* out, int64_t n, hipStream_t st) {
+  if (n == 0) return CSMOE_OK;
+  const int64_t n8 = n >> 3;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n8 + 1023) / 1024, 8192));
+  hipLaunchKernelGGL(widen_sum_kernel, dim3(grid), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c, out, n);
+  CSMOE_CHECK_LAUNCH("widen_sum");
   return CSMOE_OK;
 }
 

@@ -211,6 +211,29 @@ class RouterSelect(torch.autograd.Function):
         return ds, None, None, None, None
 
 
+class OperandFork(torch.autograd.Function):
+    """fp32 x [T, D] -> `n` bf16 operands out of ONE cast (the tensors share their storage), for the ops of a layer that each read x
+    under bf16 autocast: the reference's gate (F.linear), cvmm and shared expert cast x themselves (moe.py:121, cvmm.py:29-32,445,
+    deepseekv2.py:154-165), every cast's backward widens its bf16 gradient and the engine adds the fp32 streams.  Same values here
+    from one cast forward and one pass backward (csmoe_widen_sum: the streams in fp32, later-created consumer first, as the engine
+    meets them) instead of a cast per consumer each way and an fp32 add per pair."""
+
+    @staticmethod
+    def forward(ctx, x, n: int):
+        ctx.set_materialize_grads(False)
+        xb = x.to(torch.bfloat16)
+        twins = [torch.empty(0, dtype=xb.dtype, device=xb.device).set_(xb.untyped_storage(), xb.storage_offset(), xb.shape, xb.stride())
+                 for _ in range(n - 1)]
+        return (xb, *twins)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in reversed(gs) if g is not None]
+        if not live:
+            return None, None
+        return ops.widen_sum(live), None
+
+
 class GateSelect(torch.autograd.Function):
     """GateLogits + RouterSelect in ONE launch that reads x once (csmoe_gate_select): returns (logits, softmax fp32, idx int32,
     w fp32) with the bits the two separate functions give.  `self.gate(x)` + `topk_expert` (moe_model/model/moe/smoe.py:42-44) /

@@ -340,16 +340,39 @@ def dispatch_tokens(x2: torch.Tensor, bins: Bins) -> torch.Tensor:
 
 
 def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None,
-                      pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      pre: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
     """dx[t] = round(round(sum_k dxs[slot]) + add[t]); with `idx` [T, K] (int32) the sequential form of the LLaVA stack's autograd:
-    (((pre[t] + dxs[slot of the highest expert]) + ...) + dxs[slot of the lowest]) + add[t], rounded after every add (csmoe.h)."""
+    (((pre[t] + dxs[slot of the highest expert]) + ...) + dxs[slot of the lowest]) + add[t], rounded after every add (csmoe.h).
+    `out_f32` (bf16 rows, D % 8 == 0): dx fp32 = float(round_bf16(sum_k dxs[slot])) + float(add[t]) (csmoe_dispatch_rows_bwd_mixed)."""
     D = dxs.shape[1]
+    if out_f32:
+        if dxs.dtype != torch.bfloat16 or idx is not None or pre is not None:
+            raise ValueError("dispatch_rows_bwd(out_f32=True): bf16 rows, no sequential form")
+        dx = torch.empty(T, D, dtype=torch.float32, device=dxs.device)
+        with _timed("dispatch_rows_bwd", (T * (2 + (add is not None)) + bins.n) * D * 2):
+            L.check(lib.csmoe_dispatch_rows_bwd_mixed(dxs.data_ptr(), bins.slot_of.data_ptr(), bins.K, _ptr(add), dx.data_ptr(), T, D,
+                                                      _stream()), "dispatch_rows_bwd_mixed")
+        return dx
     dx = torch.empty(T, D, dtype=dxs.dtype, device=dxs.device)
     streams = 1 + (add is not None) + (pre is not None)
     with _timed("dispatch_rows_bwd", (T * streams + bins.n) * D * dxs.element_size()):     # `add` / `pre` are [T, D] reads
         L.check(lib.csmoe_dispatch_rows_bwd(dxs.data_ptr(), bins.slot_of.data_ptr(), bins.K, _ptr(add), dx.data_ptr(), T, D,
                                             _dt(dxs), _ptr(idx), _ptr(pre), _stream()), "dispatch_rows_bwd")
     return dx
+
+
+def widen_sum(streams) -> torch.Tensor:
+    """fp32 sum of up to three bf16 tensors of one shape, added in the order given (csmoe_widen_sum): the gradient autograd leaves in
+    an fp32 tensor whose bf16 casts fed several ops."""
+    streams = [s.contiguous() for s in streams]
+    a = streams[0]
+    if not 1 <= len(streams) <= 3 or any(s.dtype != torch.bfloat16 or s.shape != a.shape for s in streams):
+        raise ValueError("widen_sum: one to three bf16 tensors of one shape")
+    out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    p = [s.data_ptr() for s in streams] + [None] * (3 - len(streams))
+    with _timed("widen_sum", a.numel() * (2 * len(streams) + 4)):
+        L.check(lib.csmoe_widen_sum(p[0], p[1], p[2], out.data_ptr(), a.numel(), _stream()), "widen_sum")
+    return out
 
 
 def combine(y: torch.Tensor, bins: Bins, idx: torch.Tensor, w: torch.Tensor, mode: int, T: int,

@@ -98,7 +98,7 @@ class CompeteSMoE(MoE):
         affinities, renormalised weights, the K selected dense outputs for the diversity loss."""
         B, N, D = x.shape
         op = op_dtype(x)
-        x2 = x.reshape(-1, D).to(op)
+        x2 = self.operand(x)
         if self._lean_competition(x2):
             # without the [T, E, D] outputs: affinities from the second GEMM's epilogue, backward by recomputation, the selected
             # experts' outputs from the sparse step (forward below); functional.CompetitionAffinityPacked

@@ -104,8 +104,8 @@ class _CVMM(torch.autograd.Function):
         ops.grouped_wgrad(xs, gs, bins.offsets, E, gk, gk.data_ptr() + ar * (Din * Dout * gk.element_size()))
         if rows_are_slots:
             dx = ops.dispatch_rows(dxs, ops.Bins(None, None, bins.slot_of, None, bins.n, bins.E, 1))
-        else:
-            dx = ops.dispatch_rows_bwd(dxs, bins, T)
+        else:       # an fp32 x under bf16 autocast takes the widened gradient straight from the gather-sum
+            dx = ops.dispatch_rows_bwd(dxs, bins, T, out_f32=(xdt == torch.float32 and dxs.dtype == torch.bfloat16 and dxs.shape[1] % 8 == 0))
         return dx.view(xshape).to(xdt), gk, dw, None, None
 
 

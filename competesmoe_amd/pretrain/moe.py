@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from .. import ops
-from ..functional import (DenseFFN, DenseFFNFP8, GateLogits, GateSelect, MoEFFNPacked, MoEFFNPackedFP8, MoEFFNPackedSlots,
+from ..functional import (DenseFFN, DenseFFNFP8, GateLogits, GateSelect, MoEFFNPacked, MoEFFNPackedFP8, MoEFFNPackedSlots, OperandFork,
                           RouterSelect)
 from .framework_layers import LoggingLayer, OncePerIterLayer, RegularizedLayer
 
@@ -37,6 +37,11 @@ def _act_code(fn) -> int:
         if torch.allclose(out, ref, atol=1e-6):
             return code
     raise NotImplementedError("competesmoe_amd: unsupported expert activation callable")
+
+
+def _operand_fork() -> bool:
+    import os
+    return os.environ.get("CSMOE_OPERAND_FORK", "1") != "0"
 
 
 def op_dtype(x: torch.Tensor) -> torch.dtype:
@@ -117,6 +122,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         self._pre_logits = None       # gate logits computed with the LayerNorm
         self._residual = None         # the block's residual stream, added in the combine epilogue
         self._stream_dtype = None     # dtype of the tensor the reference layer would have been called with (its `x.dtype`)
+        self._twins = None            # spare bf16 operands of this forward's x (operand())
 
     _fuses_residual = False           # True on layers whose output IS one combine (smoe, competesmoe)
 
@@ -139,8 +145,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         if pre is not None:
             self._pre_logits = None
             return pre.view(*shp[:-1], -1)
-        op = op_dtype(x)
-        lg = GateLogits.apply(x.reshape(-1, shp[-1]).to(op), self.w_gate)
+        lg = GateLogits.apply(self.operand(x), self.w_gate)
         return lg.view(*shp[:-1], -1)
 
     def select(self, scores, mode, x_dtype):
@@ -151,6 +156,25 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         K = self.num_selected
         return w.view(*shp[:-1], K), idx.view(*shp[:-1], K), sm.view(shp)
 
+    def operand(self, x):
+        """x as the [T, D] operand of a kernel in the op dtype.  An fp32 x under bf16 autocast that takes gradients is cast ONCE per
+        forward: the first call forks it (functional.OperandFork), the gate / experts / shared expert each take one of the bf16
+        tensors, and x receives the fp32 sum of their gradients in one pass -- the values of the reference's separate casts.
+        CSMOE_OPERAND_FORK=0: a cast per call."""
+        op = op_dtype(x)
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype == op:
+            return x2
+        if not (op == torch.bfloat16 and x2.dtype == torch.float32 and x2.is_cuda and torch.is_grad_enabled() and x2.requires_grad
+                and _operand_fork()):
+            return x2.to(op)
+        tw = self._twins
+        if tw is not None and tw[0] is x and tw[1] == x._version and tw[2]:
+            return tw[2].pop()
+        outs = OperandFork.apply(x2.contiguous(), 3)
+        self._twins = (x, x._version, list(outs[1:]))
+        return outs[0]
+
     def gate_and_select(self, x, mode, x_dtype):
         """compute_gate + select -> (gate_logits, weights, selected_experts, gate_softmax); one launch that reads x once
         (csmoe_gate_select, same bits) when the gate is the plain F.linear and the block has not computed the logits already."""
@@ -158,7 +182,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         op = op_dtype(x)
         K, E = self.num_selected, self.w_gate.shape[0]
         if self._pre_logits is None and self._plain_gate() and op == torch.bfloat16:
-            x2 = x.reshape(-1, shp[-1]).to(op)
+            x2 = self.operand(x)
             if ops.gate_select_ok(x2, self.w_gate, K):
                 sd = self._stream_dtype if self._stream_dtype is not None else x_dtype
                 lg, sm, idx, w = GateSelect.apply(x2, self.w_gate, K, mode, sd == torch.bfloat16)
@@ -175,7 +199,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
     def ffn(self, x, selected_experts, weights, keys=None, values=None, bias=None):
         shp = x.shape
         op = op_dtype(x)
-        x2 = x.reshape(-1, shp[-1]).to(op)
+        x2 = self.operand(x)
         K = selected_experts.shape[-1]
         res = None
         if keys is None and self._residual is not None:
@@ -207,8 +231,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
     def ffn_slots(self, x, selected_experts, weights):
         """ffn() plus the selected experts' outputs per (token, k) slot [..., K, Dout] of the same pass (MoEFFNPackedSlots)."""
         shp = x.shape
-        op = op_dtype(x)
-        x2 = x.reshape(-1, shp[-1]).to(op)
+        x2 = self.operand(x)
         K = selected_experts.shape[-1]
         wk = weights.reshape(-1, K)
         out, y_tk = MoEFFNPackedSlots.apply(x2, wk.float().contiguous(), selected_experts.reshape(-1, K).int().contiguous(),
@@ -222,9 +245,9 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         op = op_dtype(x)
         b = None if bias_shared is None else bias_shared[0]
         if self.fp8_experts:
-            y = DenseFFNFP8.apply(x.reshape(-1, shp[-1]).to(op), keys_shared[0], b, values_shared[0], self.act_code, self.fp8_weight_cache)
+            y = DenseFFNFP8.apply(self.operand(x), keys_shared[0], b, values_shared[0], self.act_code, self.fp8_weight_cache)
             return y.view(*shp[:-1], -1)
-        y = DenseFFN.apply(x.reshape(-1, shp[-1]).to(op), keys_shared[0], b, values_shared[0], None, self.act_code, L.B_KN)
+        y = DenseFFN.apply(self.operand(x), keys_shared[0], b, values_shared[0], None, self.act_code, L.B_KN)
         return y.view(*shp[:-1], -1)
 
     # ------------------------------------------------------------------ losses ([B,N,E]-sized torch math)
@@ -282,6 +305,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
             self.iter += 1
 
     def _finish(self, out, x):
+        self._twins = None
         self.layer += 1
         self.was_training = self.training
         res = out.view(*x.shape[:-1], self.v_dim)

@@ -53,7 +53,7 @@ class EPSMoeLayer(SMoeLayer):
         if keys is not None or values is not None or bias is not None:
             raise ValueError("smoe_ep: the experts are the layer's own sharded tensors")
         shp = x.shape
-        x2 = x.reshape(-1, shp[-1]).to(op_dtype(x))
+        x2 = self.operand(x)
         K = selected_experts.shape[-1]
         res = None
         if self._residual is not None:

@@ -305,6 +305,17 @@ int csmoe_combine_mixed(const void* y, const int32_t* slot_of, const int32_t* id
 /* csmoe_combine_bwd with an fp32 upstream gradient, rounded to bf16 on load (the cast autograd would insert) */
 int csmoe_combine_bwd_mixed(const float* dout, const void* y, const int32_t* slot_of, const float* w, void* dy, float* dw, int T, int K,
                             int D, csmoe_stream_t stream);
+/* csmoe_dispatch_rows_bwd into the fp32 stream: dx[t,:] = float(round_bf16(sum_k dxs[slot_of[t*K+k], :])) + float(add[t,:]), the sum
+ * of the two in fp32 -- what autograd leaves in an fp32 x under bf16 autocast when the experts (CVMM.backward's bf16 reduction,
+ * cvmm.py:544-545) and the gate (F.linear's bf16 dx, moe.py:121) each read their own bf16 cast of x: every cast's backward widens
+ * its bf16 gradient and the engine adds the fp32 streams.  dxs, add (may be null): bf16; D % 8 == 0, 16-byte aligned operands. */
+int csmoe_dispatch_rows_bwd_mixed(const void* dxs, const int32_t* slot_of, int K, const void* add, float* dx, int T, int D,
+                                  csmoe_stream_t stream);
+/* out[i] = (float(a[i]) + float(b[i])) + float(c[i]), a / b / c bf16 (b, c may be null, in that order), n elements: the gradient an
+ * fp32 x receives under bf16 autocast when several ops read it -- the gate's F.linear, the experts' cvmm, the shared expert
+ * (moe.py:121, cvmm.py:29-32,445; deepseekv2.py:154-165) each cast x themselves, every cast's backward widens its bf16 stream and the
+ * autograd engine adds the fp32 streams.  One pass over the streams; 16-byte aligned operands. */
+int csmoe_widen_sum(const void* a, const void* b, const void* c, float* out, int64_t n, csmoe_stream_t stream);
 
 /* ---- competition affinity ----------------------------------------------------------------------------
  * aff[r] = mean_d softplus(y[r, d])  (competesmoe.py:242; pretrain competesmoe.py:401) and its backward

@@ -182,6 +182,38 @@ def test_combine_mixed_and_bwd(T, K, E, D):
     assert dy.dtype == torch.bfloat16 and torch.equal(dy, dy2) and torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("T,K,E,D", [(5, 2, 4, 8), (300, 2, 8, 64), (1024, 3, 16, 1152), (2048, 2, 64, 4096), (7, 1, 4, 512)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_dispatch_rows_bwd_into_the_fp32_stream(T, K, E, D, with_add):
+    """csmoe_dispatch_rows_bwd_mixed: the bf16 K-sum of CVMM.backward (cvmm.py:544-545) widened, plus a widened bf16 stream, in fp32:
+    what the bf16 kernel followed by the casts' backward and the engine's fp32 add leave (exact)."""
+    g = torch.Generator().manual_seed(3 * D + T)
+    idx = torch.rand(T, E, generator=g).topk(K, -1).indices.int().to(DEV)
+    bins = ops.bin_tokens(idx, E)
+    dxs = torch.randn(T * K, D, generator=g).bfloat16().to(DEV)
+    add = torch.randn(T, D, generator=g).bfloat16().to(DEV) if with_add else None
+    got = ops.dispatch_rows_bwd(dxs, bins, T, add=add, out_f32=True)
+    assert got.dtype == torch.float32
+    want = ops.dispatch_rows_bwd(dxs, bins, T).float()
+    if with_add:
+        want = want + add.float()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("n", [8, 13, 4096 + 5, 3 * 1024 * 1024 + 3])
+@pytest.mark.parametrize("streams", [1, 2, 3])
+def test_widen_sum_is_the_engines_fp32_accumulation(n, streams):
+    g = torch.Generator().manual_seed(n + streams)
+    ts = [(torch.randn(n, generator=g) * 10 ** i).bfloat16().to(DEV) for i in range(streams)]
+    got = ops.widen_sum(ts)
+    want = ts[0].float()
+    for t in ts[1:]:
+        want = want + t.float()
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+    with pytest.raises(ValueError):
+        ops.widen_sum([ts[0].float()])
+
+
 def test_fused_block_equals_unfused_under_autocast():
     """Same layer, same stream: the fused block against LayerNorm -> layer -> add composed from torch ops around our layer."""
     torch.manual_seed(5)

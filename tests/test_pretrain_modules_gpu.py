@@ -370,3 +370,42 @@ def test_pretrain_lean_competition_backpropagates_the_diversity_loss_through_the
         a, b = grads["1"][k], grads["0"][k]
         assert float(b.abs().max()) > 0, k
         assert rel_l2(a, b) <= 5e-3, (k, rel_l2(a, b))
+
+
+@pytest.mark.parametrize("case", ["smoe", "competesmoe_router", "competesmoe_comp", "deepseekv2", "deepseekv3"])
+def test_one_cast_of_x_per_forward_gives_the_gradients_of_a_cast_per_consumer(case, monkeypatch):
+    """functional.OperandFork (MoE.operand): an fp32 x under bf16 autocast is cast once for the gate, the experts and the shared
+    expert, and receives the fp32 sum of their bf16 gradients in one pass (csmoe_widen_sum).  The reference casts x in every
+    consumer (moe.py:121, cvmm.py:445, deepseekv2.py:154-165) and autograd adds the widened streams: same bits with two streams;
+    with three (shared-expert layers) the fp32 additions may associate differently (bound 1e-6)."""
+    from competesmoe_amd import functional as Fn
+    fx = load(f"pretrain_{case}_bf16")
+    res = {}
+    for fork in ("0", "1"):
+        monkeypatch.setenv("CSMOE_OPERAND_FORK", fork)
+        forks = []
+        orig = Fn.OperandFork.forward
+
+        def spy(ctx, *a):
+            forks.append(1)
+            return orig(ctx, *a)
+        monkeypatch.setattr(Fn.OperandFork, "forward", staticmethod(spy))
+        layer, kw = build(fx)
+        x = fx["x"].to(DEV).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = layer(x, **kw)
+            reg = sum(layer.get_reg_loss().values())
+        torch.autograd.backward([out, reg.float()], [fx["dy"].to(DEV).to(out.dtype), torch.ones((), device=DEV)])
+        monkeypatch.setattr(Fn.OperandFork, "forward", staticmethod(orig))
+        assert len(forks) == (1 if fork == "1" else 0), forks
+        assert layer._twins is None
+        assert x.grad.dtype == torch.float32
+        res[fork] = (out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None})
+    assert torch.equal(res["0"][0], res["1"][0])
+    assert res["0"][2].keys() == res["1"][2].keys()
+    for n in res["0"][2]:
+        assert torch.equal(res["0"][2][n], res["1"][2][n]), n
+    if case.startswith("deepseek"):
+        assert rel_l2(res["1"][1], res["0"][1]) <= 1e-6
+    else:
+        assert torch.equal(res["0"][1], res["1"][1])
