@@ -375,6 +375,7 @@ def main():
     x.requires_grad_(True)
     one = torch.ones((), device=dev)
     x32 = dy32 = None
+    dy_as = {}
     if a.stack == "pretrain":          # the LM's residual stream is fp32 under autocast
         x32 = x.detach().float().requires_grad_(True)
         dy32 = dy.float()
@@ -395,7 +396,11 @@ def main():
                 else:
                     out = layer(x32, id_layer=0)
                 reg = sum(layer.get_reg_loss().values())
-            torch.autograd.backward([out, reg.float()], [dy32.to(out.dtype), one])
+            # the upstream gradient in the output's dtype (bf16 under autocast, as the LLaVA stack's dy): resident input, cast once
+            g = dy_as.get(out.dtype)
+            if g is None:
+                g = dy_as[out.dtype] = dy32.to(out.dtype)
+            torch.autograd.backward([out, reg.float()], [g, one])
             return
         if blk is not None:
             out, aux, _, _ = blk(x)
