@@ -171,7 +171,7 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         tw = self._twins
         if tw is not None and tw[0] is x and tw[1] == x._version and tw[2]:
             return tw[2].pop()
-        outs = OperandFork.apply(x2.contiguous(), 3)
+        outs = OperandFork.apply(x2.contiguous(), 4)
         self._twins = (x, x._version, list(outs[1:]))
         return outs[0]
 
@@ -187,6 +187,9 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
                 sd = self._stream_dtype if self._stream_dtype is not None else x_dtype
                 lg, sm, idx, w = GateSelect.apply(x2, self.w_gate, K, mode, sd == torch.bfloat16)
                 return lg.view(*shp[:-1], E), w.view(*shp[:-1], K), idx.view(*shp[:-1], K), sm.view(*shp[:-1], E)
+            gate_logits = GateLogits.apply(x2, self.w_gate).view(*shp[:-1], E)      # compute_gate on the operand already in hand
+            w, idx, sm = self.select(gate_logits, mode, x_dtype)
+            return gate_logits, w, idx, sm
         gate_logits = self.compute_gate(x)
         w, idx, sm = self.select(gate_logits, mode, x_dtype)
         return gate_logits, w, idx, sm

@@ -372,15 +372,18 @@ def test_pretrain_lean_competition_backpropagates_the_diversity_loss_through_the
         assert rel_l2(a, b) <= 5e-3, (k, rel_l2(a, b))
 
 
-@pytest.mark.parametrize("case", ["smoe", "competesmoe_router", "competesmoe_comp", "deepseekv2", "deepseekv3"])
-def test_one_cast_of_x_per_forward_gives_the_gradients_of_a_cast_per_consumer(case, monkeypatch):
+@pytest.mark.parametrize("case,two_launch_router", [("smoe", False), ("competesmoe_router", False), ("competesmoe_comp", False),
+                                                    ("deepseekv2", False), ("deepseekv3", False), ("deepseekv2", True)])
+def test_one_cast_of_x_per_forward_gives_the_gradients_of_a_cast_per_consumer(case, two_launch_router, monkeypatch):
     """functional.OperandFork (MoE.operand): an fp32 x under bf16 autocast is cast once for the gate, the experts and the shared
     expert, and receives the fp32 sum of their bf16 gradients in one pass (csmoe_widen_sum).  The reference casts x in every
     consumer (moe.py:121, cvmm.py:445, deepseekv2.py:154-165) and autograd adds the widened streams: same bits with two streams;
     with three (shared-expert layers) the fp32 additions may associate differently (bound 1e-6)."""
-    from competesmoe_amd import functional as Fn
+    from competesmoe_amd import functional as Fn, ops
     fx = load(f"pretrain_{case}_bf16")
     res = {}
+    if two_launch_router:        # more than 64 experts (BASELINE config 5): gate GEMM + router_select on the operand already cast
+        monkeypatch.setattr(ops, "gate_select_ok", lambda *a, **k: False)
     for fork in ("0", "1"):
         monkeypatch.setenv("CSMOE_OPERAND_FORK", fork)
         forks = []
