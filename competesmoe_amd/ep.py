@@ -672,7 +672,7 @@ class EPFFNPacked(torch.autograd.Function):
                     col = ops.finish_row_dot(dot).view(-1, 1) if dot is not None else torch.empty(0, 1, dtype=torch.float32, device=dev)
                     back.append(ln.give_back(col, dots))
                 if need_params:                          # dy = round(w * upstream row), what combine_bwd hands the single-GPU d values
-                    dys = (dys.float() * wr.view(-1, 1)).to(op)
+                    dys = ops.scale_rows(dys, wr)
             else:
                 dh = ops.grouped_gemm(dys, tab.w2_ptrs[e0:e1], L.B_NK, Dout, F, lb.offsets, Ec, epilogue=L.EPI_ACTGRAD, act=tab.act, aux=aux)
             if need_dx:                                  # input gradient first: its return trip overlaps this group's weight gradients

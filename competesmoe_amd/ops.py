@@ -361,6 +361,23 @@ def dispatch_rows_bwd(dxs: torch.Tensor, bins: Bins, T: int, add: Optional[torch
     return dx
 
 
+_IDENT = {}
+
+
+def scale_rows(rows: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """round(w[m] * rows[m, :]) in rows.dtype, the product in fp32 (csmoe_combine_bwd over the identity map with K = 1): what
+    `(rows.float() * w[:, None]).to(rows.dtype)` computes in three passes."""
+    n = rows.shape[0]
+    if n == 0:
+        return rows
+    ident = _IDENT.get(rows.device)
+    if ident is None or ident.numel() < n:          # one growing index vector per device: row counts differ from step to step
+        ident = _IDENT[rows.device] = torch.arange(max(n, 2 * (0 if ident is None else ident.numel())), dtype=torch.int32, device=rows.device)
+    ar = ident[:n]
+    dy, _ = combine_bwd(rows.contiguous(), None, Bins(None, None, ar, ar, n, 1, 1), w.reshape(-1, 1).float().contiguous(), want_dw=False)
+    return dy
+
+
 def widen_sum(streams) -> torch.Tensor:
     """fp32 sum of up to three bf16 tensors of one shape, added in the order given (csmoe_widen_sum): the gradient autograd leaves in
     an fp32 tensor whose bf16 casts fed several ops."""

@@ -214,6 +214,19 @@ def test_widen_sum_is_the_engines_fp32_accumulation(n, streams):
         ops.widen_sum([ts[0].float()])
 
 
+@pytest.mark.parametrize("n,D,dtype", [(0, 64, torch.bfloat16), (5, 8, torch.bfloat16), (1000, 1152, torch.bfloat16), (4096, 4096, torch.bfloat16),
+                                       (300, 64, torch.float32)])
+def test_scale_rows_is_the_three_pass_product(n, D, dtype):
+    g = torch.Generator().manual_seed(n + D)
+    rows = torch.randn(n, D, generator=g).to(dtype).to(DEV)
+    w = torch.rand(n, generator=g).to(DEV)
+    got = ops.scale_rows(rows, w)
+    assert got.dtype == dtype and torch.equal(got, (rows.float() * w.view(-1, 1)).to(dtype))
+    bigger = torch.randn(2 * n + 3, D, generator=g).to(dtype).to(DEV)           # the cached index vector grows
+    w2 = torch.rand(2 * n + 3, generator=g).to(DEV)
+    assert torch.equal(ops.scale_rows(bigger, w2), (bigger.float() * w2.view(-1, 1)).to(dtype))
+
+
 def test_fused_block_equals_unfused_under_autocast():
     """Same layer, same stream: the fused block against LayerNorm -> layer -> add composed from torch ops around our layer."""
     torch.manual_seed(5)
