@@ -26,6 +26,10 @@ namespace {
 #endif
 constexpr int RF_WAVES = CSMOE_RF_WAVES;   // waves per workgroup, 16 token rows each
 constexpr int RF_ROWS = 16 * RF_WAVES;     // token rows per workgroup
+#ifndef CSMOE_RF_RING
+#define CSMOE_RF_RING 3
+#endif
+constexpr int RF_RING = CSMOE_RF_RING;     // x chunks held per wave: one in use, RF_RING - 1 in flight
 constexpr int RF_KCH = 256;           // K-chunk staged in LDS
 constexpr int RF_LD = RF_KCH + 8;     // bf16 elements per staged gate row (528 B)
 
@@ -56,7 +60,7 @@ __global__ void __launch_bounds__(64 * RF_WAVES) gate_select_kernel(const bf16* 
   constexpr int RPP = 2 * RF_WAVES;                           // gate rows per pass
   constexpr int NPASS = NE * 16 / RPP;
   bf16x8 wreg[NPASS];
-  bf16x8 a[3][8];                                             // ring: chunk ch in a[ch % 3], chunks ch+1 and ch+2 in flight
+  bf16x8 a[RF_RING][8];                                       // ring: chunk ch in a[ch % RF_RING], the next RF_RING - 1 in flight
   f32x4 acc[NE];
 #pragma unroll
   for (int c = 0; c < NE; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(64 * RF_WAVES) gate_select_kernel(const bf16* 
   auto step = [&](int ch, bf16x8 (&a_use)[8], bf16x8 (&a_fill)[8]) {
     const bool more = (CSMOE_RF_DIAG == 2) ? false : ch + 1 < nch;
     if (more) load_w(ch + 1);
-    if (ch + 2 < nch) load_a(a_fill, ch + 2);
+    if (ch + RF_RING - 1 < nch) load_a(a_fill, ch + RF_RING - 1);
     const bf16* wb = wbuf + ((CSMOE_RF_DIAG == 2) ? 0 : (ch & 1)) * WB + i16 * RF_LD + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -103,14 +107,15 @@ __global__ void __launch_bounds__(64 * RF_WAVES) gate_select_kernel(const bf16* 
   };
 
   load_w(0);
-  load_a(a[0], 0);
-  if (nch > 1) load_a(a[1], 1);
+#pragma unroll
+  for (int j = 0; j < RF_RING - 1; ++j)
+    if (j < nch) load_a(a[j], j);
   store_w(0);
   __syncthreads();
-  for (int ch = 0; ch < nch; ch += 3) {
-    step(ch, a[0], a[2]);
-    if (ch + 1 < nch) step(ch + 1, a[1], a[0]);
-    if (ch + 2 < nch) step(ch + 2, a[2], a[1]);
+  for (int ch = 0; ch < nch; ch += RF_RING) {
+#pragma unroll
+    for (int j = 0; j < RF_RING; ++j)
+      if (ch + j < nch) step(ch + j, a[j], a[(j + RF_RING - 1) % RF_RING]);
   }
 
 #if CSMOE_RF_DIAG == 1      // timing experiment (wrong results): the stream + MFMA loop alone, no selection
