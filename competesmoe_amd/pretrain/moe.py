@@ -123,6 +123,9 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         self._residual = None         # the block's residual stream, added in the combine epilogue
         self._stream_dtype = None     # dtype of the tensor the reference layer would have been called with (its `x.dtype`)
         self._twins = None            # spare bf16 operands of this forward's x (operand())
+        self._forking = False         # inside forward(): only there is x cast once for all its consumers, and the spares never outlive it
+        self.register_forward_pre_hook(MoE._enter_forward)
+        self.register_forward_hook(MoE._leave_forward)
 
     _fuses_residual = False           # True on layers whose output IS one combine (smoe, competesmoe)
 
@@ -156,17 +159,26 @@ class MoE(LoggingLayer, RegularizedLayer, OncePerIterLayer, nn.Module):
         K = self.num_selected
         return w.view(*shp[:-1], K), idx.view(*shp[:-1], K), sm.view(shp)
 
+    @staticmethod
+    def _enter_forward(module, args):
+        module._twins, module._forking = None, True
+
+    @staticmethod
+    def _leave_forward(module, args, output):
+        module._twins, module._forking = None, False
+
     def operand(self, x):
         """x as the [T, D] operand of a kernel in the op dtype.  An fp32 x under bf16 autocast that takes gradients is cast ONCE per
         forward: the first call forks it (functional.OperandFork), the gate / experts / shared expert each take one of the bf16
         tensors, and x receives the fp32 sum of their gradients in one pass -- the values of the reference's separate casts.
-        CSMOE_OPERAND_FORK=0: a cast per call."""
+        Only inside forward() (hooks above): a method called on its own (att_forward, a test calling ffn) casts per call, so no spare
+        tensor -- and with it the graph behind x -- outlives a forward.  CSMOE_OPERAND_FORK=0: a cast per call."""
         op = op_dtype(x)
         x2 = x.reshape(-1, x.shape[-1])
         if x2.dtype == op:
             return x2
-        if not (op == torch.bfloat16 and x2.dtype == torch.float32 and x2.is_cuda and torch.is_grad_enabled() and x2.requires_grad
-                and _operand_fork()):
+        if not (self._forking and op == torch.bfloat16 and x2.dtype == torch.float32 and x2.is_cuda and torch.is_grad_enabled()
+                and x2.requires_grad and _operand_fork()):
             return x2.to(op)
         tw = self._twins
         if tw is not None and tw[0] is x and tw[1] == x._version and tw[2]:

@@ -401,7 +401,10 @@ def test_one_cast_of_x_per_forward_gives_the_gradients_of_a_cast_per_consumer(ca
         torch.autograd.backward([out, reg.float()], [fx["dy"].to(DEV).to(out.dtype), torch.ones((), device=DEV)])
         monkeypatch.setattr(Fn.OperandFork, "forward", staticmethod(orig))
         assert len(forks) == (1 if fork == "1" else 0), forks
-        assert layer._twins is None
+        assert layer._twins is None and not layer._forking
+        with torch.autocast("cuda", dtype=torch.bfloat16):      # a method called outside forward() casts on its own: nothing is kept
+            assert layer.operand(x).dtype == torch.bfloat16
+        assert layer._twins is None and len(forks) == (1 if fork == "1" else 0)
         assert x.grad.dtype == torch.float32
         res[fork] = (out.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None})
     assert torch.equal(res["0"][0], res["1"][0])
